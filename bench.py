@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the wavefront kernel chain on MI355X.
+
+Workload (BASELINE.json configs[1]): seeded Shirley random-spheres scene, 1920x1080, 8 bounces; one STEP is
+one sample per pixel of the whole frame: generate_rays -> 8 x (extend, scan, shade, miss_kernel) -> accumulate.
+Default K = 64 steps = the 64 spp the metric is quoted on. Inputs (scene, BVH, camera) are resident in HBM
+before the timed region; the timed region holds K steps (and, for N > 1, the final RCCL gather).
+
+  python bench.py --gpus 1 --steps 64 --warmup 4
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; the frame is sharded by 8-row pixel bands (band k -> rank k % N), no collective
+inside the bounce loop, one gather of the accumulated slabs to rank 0 at the end (scaling = "strong": the
+frame is fixed, per-GPU work shrinks). Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rng-mode", choices=["auto", "dispatch", "pixel"], default="auto",
+                    help="auto: dispatch (reference-faithful) on 1 GPU, pixel (shard-invariant) on N > 1")
+    ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    ap.add_argument("--no-stage-times", action="store_true")
+    ap.add_argument("--dump", default=None, help="write the tone-mapped frame (PPM) here (rank 0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, rng_mode):
+    """The oracle (kind "port": the build's own CPU restatement of the reference's chain; the reference's
+    cpu_wavefront_pt has no source) timed on this box's host cores, OpenMP, on a bounded sample of the SAME
+    workload: same scene/seed/camera/size/bounces, fewer samples per pixel (Mrays/s is spp-invariant)."""
+    from oracle import oracle as O
+    o = O.shirley_oracle(args.width, args.height, seed=args.seed, max_wavefronts=args.bounces, rng_mode=rng_mode)
+    t0 = time.perf_counter()
+    spp = 0
+    while True:
+        o.render_sample()
+        spp += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or spp >= 4:
+            break
+    rays = int(o.totals()[0])
+    cores = O.lib().orc_num_threads()
+    o.close()
+    return {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{spp} of the workload's samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
+                      f"{rays} rays, {el:.1f} s, OpenMP x{cores})"}
+
+
+def load_traffic():
+    """HBM bytes per extend launch from the committed PMC summary, if one exists (profiles/*_pmc_extend.json)."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_extend*.json"))):
+        try:
+            best = json.load(open(p))
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import wavefront_path_tracer_amd as W
+    from wavefront_path_tracer_amd import tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available() or W.device_count() < 1:
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    mode_name = args.rng_mode if args.rng_mode != "auto" else ("dispatch" if world == 1 else "pixel")
+    rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
+    flags = (W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0)
+    pt = W.shirley_path_tracer(args.width, args.height, seed=args.seed, max_wavefronts=args.bounces,
+                               rng_mode=rng_mode, flags=flags, tile_rank=rank, tile_world=world, device=local_rank)
+
+    def sync():
+        pt.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def gather():
+        if world == 1:
+            return None
+        return tiles.gather_slabs(pt.copy_accumulated_to_device, rank, world, args.width, args.height,
+                                  device=dev)
+
+    pt.render(args.warmup)
+    if world > 1:
+        gather()  # warm the communicator too
+    pt.reset_accumulated()
+    sync()
+    rays0 = pt.totals().copy()
+    t0 = time.perf_counter()
+    pt.render(args.steps)          # EXACTLY K steps
+    frame = gather()               # the job's only collective
+    sync()
+    elapsed = time.perf_counter() - t0
+    rays = pt.totals() - rays0     # [rays traced by extend, hits, misses] on this rank
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor(rays.astype(np.int64), device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total = r.cpu().numpy().astype(np.uint64)
+    else:
+        rays_total = rays
+    if world == 1:
+        frame = pt.accumulated()
+
+    # ---- per-stage times and the extend roofline: same K steps again with hipEvent pairs around every
+    # launch on the context's stream (a second pass, so the events do not perturb `value`)
+    stage = None
+    if not args.no_stage_times:
+        ms = np.zeros(W.STAGE_COUNT, np.float64)
+        launches = np.zeros(W.STAGE_COUNT, np.int64)
+        r0 = pt.totals().copy()
+        for _ in range(args.steps):
+            m, l = pt.render_sample_timed()
+            ms += m
+            launches += l
+        rt = pt.totals() - r0
+        ext_ms, ext_n = float(ms[W.STAGES["extend"]]), int(launches[W.STAGES["extend"]])
+        ext_bytes = 24.0 * float(rt[0]) + 12.0 * float(rt[1]) + 4.0 * float(rt[2])  # 24 B/ray in, 12 B/hit, 4 B/miss
+        shade_ms = float(sum(ms[W.STAGES[k]] for k in ("shade", "shade_lambertian", "shade_metal", "shade_dielectric")))
+        stage = {"ms": {k: round(float(ms[v]), 4) for k, v in W.STAGES.items() if launches[v]},
+                 "launches": {k: int(launches[v]) for k, v in W.STAGES.items() if launches[v]},
+                 "rays": int(rt[0]), "ext_ms": ext_ms, "ext_n": ext_n, "ext_bytes": ext_bytes,
+                 "extend_shade_mrays_s": float(rt[0]) / ((ext_ms + float(ms[W.STAGES["scan"]]) + shade_ms) * 1e-3) / 1e6}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "Mrays/s (extend+shade) at 1920x1080, 64 spp, 8 bounces; 1/2/4/8 GPU",
+        "value": round(float(rays_total[0]) / elapsed / 1e6, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,  # the reference publishes no number for this metric
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"Shirley random-spheres (scene.rs:48-107, seed {args.seed}), {args.width}x{args.height}, "
+                               f"{args.steps} spp, {args.bounces} bounces",
+                   "step": "one sample per pixel: generate_rays -> bounces x (extend, scan, shade, miss_kernel) -> accumulate",
+                   "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
+                   "launch": "direct" if args.no_graph else "hipGraph",
+                   "parallelism": "single GPU" if world == 1 else f"pixel bands of 8 rows over {world} GPUs + 1 RCCL gather",
+                   "rays_traced": int(rays_total[0])},
+    }
+    if stage is not None:
+        per_launch_bytes = stage["ext_bytes"] / max(stage["ext_n"], 1)
+        avg_s = stage["ext_ms"] * 1e-3 / max(stage["ext_n"], 1)
+        achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = load_traffic()
+        out["roofline"] = {"kernel": "extend_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                           "algorithmic_bytes_per_launch": round(per_launch_bytes, 1),
+                           "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["ext_n"],
+                           "note": "extend is LDS/VALU-bound on this LDS-resident scene; see DESIGN.md"}
+        out["stage_ms"] = stage["ms"]
+        out["stage_launches"] = stage["launches"]
+        out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, rng_mode)
+    if args.dump and frame is not None:
+        rgb = W.tonemap_rgb8(frame, args.steps)
+        with open(args.dump, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (args.width, args.height))
+            f.write(rgb.tobytes())
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,271 @@
+/*
+ * wfpt.h -- C ABI of the MI355X-native wavefront path-tracing kernel chain
+ *           generate_rays -> extend -> shade -> miss_kernel -> accumulate.
+ *
+ * Drop-in boundary for ONE path of rchiaramo/wavefront_path_tracer @ 2024_10_08: the kernel-stage API
+ * `Kernel::new / Kernel::run / Kernel::get_timing` (gpu_wavefront_pt/src/kernel.rs:26-146) together with the
+ * buffers and the wavefront loop `PathTracer::new / run` owns (gpu_wavefront_pt/src/path_tracer.rs:43-371).
+ * Everything here is `extern "C"`, plain pointers and sizes; struct layouts are byte-identical to the
+ * `#[repr(C)]` structs of `wavefront_common` that the reference uploads with bytemuck::cast_slice
+ * (path_tracer.rs:120-156), so a Rust `-sys` shim can pass them through unchanged.
+ *
+ * Conventions: functions returning `int` return WFPT_OK (0) or a negative wfpt_status and never throw;
+ * `wfpt_last_error` gives the message. A context is bound to one HIP device and one stream; it is not
+ * thread-safe, independent contexts may be used from different threads/processes (one per GPU).
+ * Calls are asynchronous on the context's stream unless they read data back.
+ *
+ * All citations are relative to the reference root.
+ */
+#ifndef WFPT_H
+#define WFPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ data model (wavefront_common) */
+
+/* wavefront_common/src/sphere.rs:3-11 == extend.wgsl:10-15. center.w is 1.0 (sphere.rs:18-20). */
+typedef struct wfpt_sphere {
+    float center[4];
+    float radius;
+    uint32_t material_idx;
+    uint32_t material_type;
+    uint32_t _buffer;
+} wfpt_sphere;
+
+/* wavefront_common/src/material.rs:12-20 == shade.wgsl:19-24. 0 Lambertian, 1 Metal, 2 Dielectric. */
+typedef struct wfpt_material {
+    float albedo[4];
+    float fuzz;
+    float refract_index;
+    uint32_t material_type;
+    uint32_t _buffer;
+} wfpt_material;
+
+/* wavefront_common/src/bvh.rs:38-45 == extend.wgsl:3-8. prim_count > 0: leaf, left_first = first
+ * sphere; else left_first = left child and right child = left_first + 1. nodes[1] is a pad (bvh.rs:160). */
+typedef struct wfpt_bvh_node {
+    float aabb_min[3];
+    uint32_t left_first;
+    float aabb_max[3];
+    uint32_t prim_count;
+} wfpt_bvh_node;
+
+/* wavefront_common/src/camera_controller.rs:161-185 == generate_rays.wgsl:13-19 */
+typedef struct wfpt_gpu_camera {
+    float position[4];
+    float pitch;
+    float yaw;
+    float defocus_radius;
+    float focus_distance;
+} wfpt_gpu_camera;
+
+/* wavefront_common/src/gpu_structs.rs:5-12 == generate_rays.wgsl:21-26 */
+typedef struct wfpt_frame_buffer {
+    uint32_t width;
+    uint32_t height;
+    uint32_t frame;
+    uint32_t sample_number;
+} wfpt_frame_buffer;
+
+/* extend.wgsl:17-22: the reference's device Ray. Used only by the read-back functions; on the device
+ * rays live in SoA planes. */
+typedef struct wfpt_ray {
+    float origin[4];
+    float direction[4];
+    float inv_direction[3];
+    uint32_t pixel_idx;
+} wfpt_ray;
+
+/* extend.wgsl:24-29 */
+typedef struct wfpt_hit_payload {
+    float t;
+    uint32_t ray_idx;
+    uint32_t sphere_idx;
+    uint32_t mat_type;
+} wfpt_hit_payload;
+
+/* ------------------------------------------------------------------ enums */
+
+typedef enum wfpt_status {
+    WFPT_OK = 0,
+    WFPT_ERR_INVALID_ARGUMENT = -1,
+    WFPT_ERR_HIP = -2,          /* a HIP runtime call failed; message holds hipGetErrorString */
+    WFPT_ERR_OUT_OF_MEMORY = -3,
+    WFPT_ERR_UNSUPPORTED = -4,  /* e.g. BVH deeper than the traversal supports */
+    WFPT_ERR_NO_DEVICE = -5     /* no gfx950 device visible: there is NO CPU fallback */
+} wfpt_status;
+
+/* Stage names are the reference's shader basenames (kernel.rs:32; call sites path_tracer.rs:162,167,175,
+ * 180,185). wfpt_stage_from_name maps the strings. The three per-material stages implement the
+ * reference's README to-do "split shade into by-material shade kernels" (README.md:19). */
+typedef enum wfpt_stage {
+    WFPT_STAGE_GENERATE_RAYS = 0, /* "generate_rays" */
+    WFPT_STAGE_EXTEND = 1,        /* "extend"        */
+    WFPT_STAGE_SHADE = 2,         /* "shade"         */
+    WFPT_STAGE_MISS = 3,          /* "miss_kernel"   */
+    WFPT_STAGE_ACCUMULATE = 4,    /* "accumulate"    */
+    WFPT_STAGE_SHADE_LAMBERTIAN = 5,
+    WFPT_STAGE_SHADE_METAL = 6,
+    WFPT_STAGE_SHADE_DIELECTRIC = 7,
+    WFPT_STAGE_SCAN = 8, /* internal helper launched with extend (queue positions + loop control); only
+                            appears in wfpt_render_sample_timed's per-stage times */
+    WFPT_STAGE_COUNT = 9
+} wfpt_stage;
+
+/* How shade keys its RNG (shade.wgsl:72 uses the dispatch's global_invocation_id):
+ *  DISPATCH: exactly that, with every atomicAdd resolved in ascending thread index (stable queues).
+ *            One legal execution of the reference; the default.
+ *  PIXEL:    keyed by the ray's own pixel (x = pixel_idx % W, y = pixel_idx / W). Deviates from
+ *            shade.wgsl:72, but makes the image independent of queue order, which tile sharding across
+ *            GPUs and the per-material split need to be bit-identical to a single-queue render. */
+typedef enum wfpt_rng_mode { WFPT_RNG_DISPATCH = 0, WFPT_RNG_PIXEL = 1 } wfpt_rng_mode;
+
+enum {
+    WFPT_FLAG_SPLIT_SHADE = 1u << 0, /* fused loop runs the three per-material shade stages */
+    WFPT_FLAG_NO_GRAPH = 1u << 1     /* fused loop launches kernels directly instead of replaying a hipGraph */
+};
+
+#define WFPT_INACTIVE_PIXEL 0xffffffffu
+
+typedef struct wfpt_params {
+    uint32_t width;          /* viewport (RenderParameters::viewport_size, parameters.rs:43-45) */
+    uint32_t height;
+    uint32_t max_pixels;     /* buffer capacity, the reference's max_window_size (path_tracer.rs:44); 0 = width*height */
+    uint32_t max_wavefronts; /* path_tracer.rs:323: 50 */
+    uint32_t miss_floor;     /* path_tracer.rs:332: loop exits before shading when misses < 128 */
+    uint32_t rng_mode;       /* wfpt_rng_mode */
+    uint32_t flags;          /* WFPT_FLAG_* */
+    uint32_t tile_rank;      /* pixel-tile sharding: this context owns the 8-pixel-high bands k with */
+    uint32_t tile_world;     /*   k % tile_world == tile_rank; 0 or 1 = whole image */
+    int32_t device;          /* HIP device ordinal */
+} wfpt_params;
+
+typedef struct wfpt_ctx wfpt_ctx;
+
+/* ------------------------------------------------------------------ host-side data model helpers
+ * (no GPU needed). They restate wavefront_common so a host without the Rust crate can build inputs. */
+
+/* scene.rs:12-46: 5 spheres, 5 materials; arrays need capacity 5. Returns the count. */
+uint32_t wfpt_scene_new(wfpt_sphere *spheres, wfpt_material *materials);
+/* scene.rs:48-107 with a SEEDED generator (the reference's thread_rng is unseeded): PCG32 stream 54,
+ * f32 = top 24 bits * 2^-24, same distributions and draw order. Returns the count (<= 488), or 0 if
+ * capacity is too small. */
+uint32_t wfpt_scene_book_one_final(uint64_t seed, wfpt_sphere *spheres, wfpt_material *materials, uint32_t capacity);
+/* bvh.rs:147-210 (4096-bin SAH): reorders `spheres` in place, writes at most 2*n nodes. */
+int wfpt_build_bvh(wfpt_sphere *spheres, uint32_t n_spheres, wfpt_bvh_node *nodes, uint32_t node_capacity,
+                   uint32_t *n_nodes);
+/* camera.rs:11-24 */
+void wfpt_camera_new(const float look_from[3], const float look_at[3], float *pitch, float *yaw);
+/* camera.rs:41-69: world-from-camera, 16 floats column-major (columns right, up, dir, position) */
+void wfpt_view_transform(const float position[3], float pitch, float yaw, float view[16]);
+/* projection_matrix.rs:21-37: inverse projection, 16 floats column-major */
+void wfpt_p_inv(float vfov_rad, float aspect_ratio, float z_near, float z_far, float p_inv[16]);
+/* camera_controller.rs:173-185 */
+void wfpt_gpu_camera_new(const float position[3], float pitch, float yaw, float defocus_angle_rad,
+                         float focus_distance, wfpt_gpu_camera *out);
+/* f32::to_radians */
+float wfpt_to_radians(float degrees);
+/* path_tracer.rs:282-289. The reference panics for x <= 64; this returns (1,1) there. */
+void wfpt_workgroup_size_64(uint32_t x, uint32_t *gx, uint32_t *gy);
+/* kernel.rs:32: shader basename -> stage; -1 if unknown */
+int wfpt_stage_from_name(const char *name);
+const char *wfpt_stage_name(int stage);
+
+/* ------------------------------------------------------------------ context: PathTracer::new (path_tracer.rs:43-217) */
+
+int wfpt_device_count(void);
+/* Copies every input; no pointer is retained. Returns NULL on failure (wfpt_last_error(NULL)). */
+wfpt_ctx *wfpt_create(const wfpt_params *params,
+                      const wfpt_sphere *spheres, uint32_t n_spheres,
+                      const wfpt_material *materials, uint32_t n_materials,
+                      const wfpt_bvh_node *nodes, uint32_t n_nodes,
+                      const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]);
+void wfpt_destroy(wfpt_ctx *ctx);
+const char *wfpt_last_error(const wfpt_ctx *ctx);
+
+/* frame_buffer.queue_for_gpu (path_tracer.rs:296-297, 366-367) */
+int wfpt_set_frame(wfpt_ctx *ctx, const wfpt_frame_buffer *frame);
+/* update_buffers (path_tracer.rs:240-277): new camera / matrices / viewport; zeroes the accumulated image
+ * and resets progress exactly as the reference does on any parameter change. */
+int wfpt_update_render_parameters(wfpt_ctx *ctx, uint32_t width, uint32_t height, const wfpt_gpu_camera *camera,
+                                  const float inv_proj[16], const float view[16]);
+/* counter_buffer protocol (path_tracer.rs:313-316, 335-336, 352; extend.wgsl:41):
+ * [0] miss count, [1] hit count, [2] rays in for extend / extension rays out of shade, [3..15] unused. */
+int wfpt_set_counters(wfpt_ctx *ctx, const uint32_t counters[16]);
+int wfpt_read_counters(wfpt_ctx *ctx, uint32_t counters[16]); /* blocking, like wgpu_state.rs:132-147 */
+int wfpt_reset_image(wfpt_ctx *ctx);       /* image <- 1.0 (path_tracer.rs:305-306) */
+int wfpt_reset_accumulated(wfpt_ctx *ctx); /* accumulated <- 0 (path_tracer.rs:248-250) */
+int wfpt_clear_ray_queues(wfpt_ctx *ctx);  /* path_tracer.rs:309-310 */
+/* copy_buffer_to_buffer(extension_ray_buffer -> ray_buffer) (path_tracer.rs:348, wgpu_state.rs:115-130)
+ * done as a pointer swap. */
+int wfpt_swap_ray_queues(wfpt_ctx *ctx);
+
+/* Kernel::run((gx, gy)) (kernel.rs:107-140): gx*gy workgroups of 64 threads, thread index linearised as
+ * in the shaders (workgroup_index*64 + local_index). Semantics per stage follow the WGSL entry points:
+ *   generate_rays: width = 8*gx, height = 8*gy, one ray per thread (generate_rays.wgsl:42-91)
+ *   extend:        threads idx < counters[2] trace; counters[1] += hits, counters[0] += misses (extend.wgsl:47-70)
+ *   shade:         threads idx < counters[1]; counters[2] += rays emitted (shade.wgsl:56-156)
+ *   miss_kernel:   threads idx < counters[0] (miss_kernel.wgsl:13-38)
+ *   accumulate:    threads idx < pixel count (accumulate.wgsl:4-17; the reference has no guard)
+ * counters[0] and [1] must be zero when extend runs and counters[2] zero when shade runs, as the
+ * reference's host guarantees (path_tracer.rs:335-336, 352). */
+int wfpt_kernel_run(wfpt_ctx *ctx, int stage, uint32_t gx, uint32_t gy);
+/* Kernel::get_timing (kernel.rs:142-146, query_gpu.rs:26-43): blocks, returns the running mean (us) of
+ * the last <= 10 timed dispatches of that stage; 0 if it never ran. */
+float wfpt_kernel_timing_us(wfpt_ctx *ctx, int stage);
+
+/* PathTracer::run for one sample (path_tracer.rs:291-368) with the whole wavefront loop resident on the
+ * device: frame += 1, image <- 1, generate, up to max_wavefronts x (extend, shade, miss) with the
+ * `misses < miss_floor` exit evaluated on the device, accumulate. No host synchronisation. Sizes that
+ * are not multiples of 8 use true-size semantics: out-of-image lanes emit inactive rays. */
+int wfpt_render_sample(wfpt_ctx *ctx);
+int wfpt_render(wfpt_ctx *ctx, uint32_t n_samples);
+int wfpt_synchronize(wfpt_ctx *ctx);
+uint32_t wfpt_frame(const wfpt_ctx *ctx);               /* RenderProgress.frame */
+uint32_t wfpt_accumulated_samples(const wfpt_ctx *ctx); /* RenderProgress.accumulated_samples */
+float wfpt_progress(const wfpt_ctx *ctx, uint32_t spp); /* PathTracer::progress (path_tracer.rs:219-221) */
+/* Same loop with hipEvent pairs around every stage launch; adds the elapsed milliseconds per stage
+ * into stage_ms[WFPT_STAGE_COUNT] (+= , caller zeroes) and counts launches in stage_launches (may be
+ * NULL). Blocks until the sample is done. */
+int wfpt_render_sample_timed(wfpt_ctx *ctx, float *stage_ms, uint32_t *stage_launches);
+
+/* ------------------------------------------------------------------ read-back (blocking) */
+
+uint32_t wfpt_n_pixels(const wfpt_ctx *ctx);  /* pixels held by this context (whole 8-row bands when sharded) */
+uint32_t wfpt_ray_capacity(const wfpt_ctx *ctx);
+/* accumulated_image_buffer / image_buffer: 3 floats per pixel, stride 12, row-major (accumulate.wgsl:1-2) */
+int wfpt_read_accumulated(wfpt_ctx *ctx, float *rgb, size_t n_floats);
+int wfpt_read_image(wfpt_ctx *ctx, float *rgb, size_t n_floats);
+/* device-to-device copy of the accumulated slab on the context's stream (for a RCCL gather) */
+int wfpt_copy_accumulated_to_device(wfpt_ctx *ctx, void *device_ptr, size_t n_bytes);
+/* Queues in the reference's own layouts and in its (ascending-thread-index) order. */
+int wfpt_read_rays(wfpt_ctx *ctx, wfpt_ray *rays, uint32_t n);
+int wfpt_read_extension_rays(wfpt_ctx *ctx, wfpt_ray *rays, uint32_t n);
+int wfpt_read_hits(wfpt_ctx *ctx, wfpt_hit_payload *hits, uint32_t n);
+int wfpt_read_misses(wfpt_ctx *ctx, uint32_t *ray_indices, uint32_t n);
+/* test/bench input injection: overwrite the first n rays of the current ray queue */
+int wfpt_write_rays(wfpt_ctx *ctx, const wfpt_ray *rays, uint32_t n);
+/* Per-bounce table of the last fused sample: rows of (rays_in, hits, misses, shaded). */
+int wfpt_read_bounce_table(wfpt_ctx *ctx, uint32_t *rows4, uint32_t max_rows, uint32_t *n_rows);
+/* Totals since creation over fused samples: [0] rays traced by extend, [1] hits, [2] misses. */
+int wfpt_read_totals(wfpt_ctx *ctx, uint64_t totals[3]);
+/* display_shader.wgsl:50-52 tone map, sqrt(acc / n_samples) -> 8-bit RGB (host side, for image dumps) */
+void wfpt_tonemap_rgb8(const float *accumulated, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb);
+
+/* ------------------------------------------------------------------ diagnostics */
+/* Runs the device math primitives over arrays (op: 0 sqrt(a), 1 a/b, 2 sin(a), 3 cos(a), 4 pow(a,b),
+ * 5 f32(u32 bits of a)*2^-32, 6 min(a,b), 7 max(a,b)); used by the parity tests to prove the device
+ * arithmetic matches the oracle's bit for bit. */
+int wfpt_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+/* Static facts about the built library, e.g. "gfx950;chunk=512;..." */
+const char *wfpt_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFPT_H */

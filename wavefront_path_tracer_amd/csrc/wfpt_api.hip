@@ -1,0 +1,870 @@
+// wfpt_api.hip -- context and C ABI (include/wfpt.h) over the gfx950 kernels.
+//
+// Mirrors what PathTracer::new allocates and what PathTracer::run drives (gpu_wavefront_pt/src/
+// path_tracer.rs:43-371) and the per-stage Kernel::run / get_timing API (gpu_wavefront_pt/src/kernel.rs).
+// There is no CPU fallback: without a HIP device every device entry point fails with WFPT_ERR_NO_DEVICE.
+#include "wfpt_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+using namespace wfpt;
+
+namespace {
+thread_local std::string g_last_error;
+
+struct StageTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool pending = false;
+    std::deque<double> window; // QueryResults::running_avg, query_gpu.rs:16,26-43 (10 deep)
+};
+} // namespace
+
+struct wfpt_ctx {
+    wfpt_params p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t width = 0, height = 0;
+    uint32_t tiles_x = 0, tiles_y_local = 0;
+    uint32_t n_pixels = 0;      // pixels in this context's slab
+    uint32_t pixel_capacity = 0;
+    uint32_t capacity = 0;      // ray-queue slots (multiple of kChunk)
+    uint32_t n_chunks_max = 0;
+    bool has_inactive = false;
+    Tiling tile{0, 1};
+
+    float *ray_mem[2] = {nullptr, nullptr};
+    RayQueue q[2]{};
+    int cur = 0; // which queue is "ray_buffer"; the other one is "extension_ray_buffer"
+    float *hit_t = nullptr;
+    uint32_t *hit_prim = nullptr, *hit_ridx = nullptr, *miss_ridx = nullptr;
+    uint32_t *chunk_hits = nullptr, *chunk_miss = nullptr, *chunk_hit_base = nullptr, *chunk_miss_base = nullptr;
+    float *image = nullptr, *accumulated = nullptr;
+    Control *ctl = nullptr;
+    CameraDev *camera = nullptr;
+    wfpt_bvh_node *d_nodes = nullptr;
+    float4 *d_sphere_geom = nullptr;
+    uint16_t *d_pair_parent = nullptr;
+    wfpt_sphere *d_spheres = nullptr;
+    wfpt_material *d_materials = nullptr;
+    SceneDev scene{};
+    std::vector<wfpt_sphere> h_spheres;
+
+    uint32_t extend_grid = 0, consumer_grid = 0, accumulate_grid = 0;
+    uint32_t progress_frame = 0, accumulated_samples = 0;
+    bool dev_frame_valid = false;
+
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+
+    StageTimer timers[WFPT_STAGE_COUNT];
+    std::vector<hipEvent_t> sample_events; // for wfpt_render_sample_timed
+    std::string err;
+};
+
+namespace {
+
+int fail(wfpt_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    g_last_error = msg;
+    return code;
+}
+int hip_fail(wfpt_ctx *c, hipError_t e, const char *what) {
+    return fail(c, e == hipErrorOutOfMemory ? WFPT_ERR_OUT_OF_MEMORY : WFPT_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define WFPT_HIP(c, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(c, e_, #call); \
+    } while (0)
+
+template <typename T> hipError_t dmalloc(T **p, size_t n) {
+    return hipMalloc(reinterpret_cast<void **>(p), sizeof(T) * (n ? n : 1));
+}
+
+void set_queue(RayQueue &q, float *base, size_t cap) {
+    q.ox = base; q.oy = base + cap; q.oz = base + 2 * cap;
+    q.dx = base + 3 * cap; q.dy = base + 4 * cap; q.dz = base + 5 * cap;
+    q.pixel = reinterpret_cast<uint32_t *>(base + 6 * cap);
+}
+
+// Geometry of the viewport for this context (band sharding included).
+void set_viewport(wfpt_ctx *c, uint32_t w, uint32_t h) {
+    c->width = w;
+    c->height = h;
+    c->tiles_x = (w + 7) / 8;
+    const uint32_t tiles_y = (h + 7) / 8;
+    const uint32_t rank = c->tile.rank, world = c->tile.world;
+    c->tiles_y_local = tiles_y > rank ? (tiles_y - rank + world - 1) / world : 0;
+    c->n_pixels = world <= 1 ? w * h : c->tiles_y_local * 8u * w;
+    c->has_inactive = (w % 8u) != 0 || (h % 8u) != 0;
+}
+
+// The traversal needs siblings at (2k, 2k+1), which BVHTree::subdivide guarantees (bvh.rs:160-161,
+// 191-206), and at most 63 levels. Returns the tree depth or a negative status.
+int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint32_t n_spheres,
+                 std::vector<uint16_t> &pair_parent) {
+    if (n_nodes == 0 || n_nodes > 65536u) return fail(c, WFPT_ERR_UNSUPPORTED, "BVH must have 1..65536 nodes");
+    pair_parent.assign(((n_nodes / 2u + 1u) + 7u) / 8u * 8u, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
+    uint32_t max_depth = 0, visited = 0;
+    while (!todo.empty()) {
+        auto [i, d] = todo.back();
+        todo.pop_back();
+        if (++visited > n_nodes) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "BVH has a cycle");
+        max_depth = std::max(max_depth, d);
+        const wfpt_bvh_node &nd = nodes[i];
+        if (nd.prim_count > 0) {
+            if (static_cast<uint64_t>(nd.left_first) + nd.prim_count > n_spheres)
+                return fail(c, WFPT_ERR_INVALID_ARGUMENT, "BVH leaf references spheres out of range");
+        } else {
+            const uint32_t l = nd.left_first;
+            if (l < 2 || (l & 1u) || l + 1 >= n_nodes)
+                return fail(c, WFPT_ERR_UNSUPPORTED, "BVH children must sit at (2k, 2k+1), k >= 1 (bvh.rs layout)");
+            pair_parent[l >> 1] = static_cast<uint16_t>(i);
+            todo.push_back({l, d + 1});
+            todo.push_back({l + 1, d + 1});
+        }
+    }
+    if (max_depth > static_cast<uint32_t>(kMaxTrailDepth))
+        return fail(c, WFPT_ERR_UNSUPPORTED, "BVH deeper than 63 levels");
+    return static_cast<int>(max_depth);
+}
+
+void destroy_graph(wfpt_ctx *c) {
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
+// ---------------------------------------------------------------- argument builders
+GenerateArgs generate_args(wfpt_ctx *c, uint32_t gx, uint32_t gy, bool fused) {
+    GenerateArgs a{};
+    a.q = c->q[c->cur];
+    a.image = c->image;
+    a.ctl = c->ctl;
+    a.camera = c->camera;
+    a.gx = gx; a.gy = gy;
+    a.true_size = fused ? 1u : 0u;
+    a.reset_image = fused ? 1u : 0u;
+    a.set_n_in = fused ? 1u : 0u;
+    a.capacity = c->capacity;
+    a.tile = c->tile;
+    return a;
+}
+ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit) {
+    ExtendArgs a{};
+    a.q = c->q[qi];
+    a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
+    a.miss_ridx = c->miss_ridx;
+    a.chunk_hits = c->chunk_hits;
+    a.chunk_miss = c->chunk_miss;
+    a.ctl = c->ctl;
+    a.n_in = n_in;
+    a.limit = std::min(limit, c->capacity);
+    a.has_inactive = c->has_inactive ? 1u : 0u;
+    a.scene = c->scene;
+    return a;
+}
+ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce) {
+    ScanArgs a{};
+    a.chunk_hits = c->chunk_hits; a.chunk_miss = c->chunk_miss;
+    a.chunk_hit_base = c->chunk_hit_base; a.chunk_miss_base = c->chunk_miss_base;
+    a.ctl = c->ctl;
+    a.n_in = n_in;
+    a.limit = std::min(limit, c->capacity);
+    a.fused = fused ? 1u : 0u;
+    a.miss_floor = c->p.miss_floor;
+    a.bounce = bounce;
+    return a;
+}
+ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit, uint32_t gx, uint32_t material,
+                     bool count_out) {
+    ShadeArgs a{};
+    a.q = c->q[qi];
+    a.ext = c->q[qi ^ 1];
+    a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
+    a.chunk_hits = c->chunk_hits; a.chunk_hit_base = c->chunk_hit_base;
+    a.image = c->image;
+    a.ctl = c->ctl;
+    a.n_hits = n_hits;
+    a.limit = std::min(limit, c->capacity);
+    a.gx = gx;
+    a.rng_mode = c->p.rng_mode;
+    a.material = material;
+    a.count_out = count_out ? 1u : 0u;
+    a.image_width = c->width;
+    a.scene = c->scene;
+    a.tile = c->tile;
+    return a;
+}
+MissArgs miss_args(wfpt_ctx *c, int qi, const uint32_t *n_miss, uint32_t limit) {
+    MissArgs a{};
+    a.q = c->q[qi];
+    a.miss_ridx = c->miss_ridx;
+    a.chunk_miss = c->chunk_miss; a.chunk_miss_base = c->chunk_miss_base;
+    a.image = c->image;
+    a.ctl = c->ctl;
+    a.n_miss = n_miss;
+    a.limit = std::min(limit, c->capacity);
+    a.image_width = c->width;
+    a.tile = c->tile;
+    return a;
+}
+AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping) {
+    AccumulateArgs a{};
+    a.image = c->image;
+    a.accumulated = c->accumulated;
+    a.ctl = c->ctl;
+    a.n_floats = 3u * std::min(n_pixels, c->n_pixels);
+    a.bookkeeping = bookkeeping ? 1u : 0u;
+    return a;
+}
+
+// One fused sample on the stream (pt:291-368). `ev`: optional (stage, start, stop) event recorder.
+struct EventRec { int stage; hipEvent_t start, stop; };
+int enqueue_sample(wfpt_ctx *c, std::vector<EventRec> *ev) {
+    size_t next_event = 0;
+    auto timed = [&](int stage, auto &&launch) -> hipError_t {
+        if (!ev) return launch();
+        if (next_event + 2 > c->sample_events.size()) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t e;
+                hipError_t r = hipEventCreate(&e);
+                if (r != hipSuccess) return r;
+                c->sample_events.push_back(e);
+            }
+        }
+        hipEvent_t s = c->sample_events[next_event], t = c->sample_events[next_event + 1];
+        next_event += 2;
+        hipError_t r = hipEventRecord(s, c->stream);
+        if (r != hipSuccess) return r;
+        r = launch();
+        if (r != hipSuccess) return r;
+        r = hipEventRecord(t, c->stream);
+        ev->push_back({stage, s, t});
+        return r;
+    };
+    c->cur = 0;
+    const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
+    WFPT_HIP(c, timed(WFPT_STAGE_GENERATE_RAYS,
+                      [&] { return launch_generate(generate_args(c, c->tiles_x, c->tiles_y_local, true), c->stream); }));
+    for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+        const int qi = static_cast<int>(b & 1u);
+        WFPT_HIP(c, timed(WFPT_STAGE_EXTEND, [&] {
+                     return launch_extend(extend_args(c, qi, &c->ctl->n_in, c->capacity), c->extend_grid, c->stream);
+                 }));
+        WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
+                          [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b), c->stream); }));
+        if (split) {
+            for (uint32_t m = 0; m < 3; ++m)
+                WFPT_HIP(c, timed(WFPT_STAGE_SHADE_LAMBERTIAN + static_cast<int>(m), [&] {
+                             return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, m, false),
+                                                 c->consumer_grid, c->stream);
+                         }));
+        } else {
+            WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] {
+                         return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false),
+                                             c->consumer_grid, c->stream);
+                     }));
+        }
+        WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] {
+                     return launch_miss(miss_args(c, qi, &c->ctl->miss_n, c->capacity), c->consumer_grid, c->stream);
+                 }));
+    }
+    WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
+                 return launch_accumulate(accumulate_args(c, c->n_pixels, true), c->accumulate_grid, c->stream);
+             }));
+    return WFPT_OK;
+}
+
+int ensure_device_frame(wfpt_ctx *c) {
+    if (c->dev_frame_valid) return WFPT_OK;
+    const wfpt_frame_buffer f{c->width, c->height, c->progress_frame + 1u, 0u}; // parameters.rs:78-83; pt:296
+    WFPT_HIP(c, hipMemcpyAsync(&c->ctl->frame, &f, sizeof f, hipMemcpyHostToDevice, c->stream));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    c->dev_frame_valid = true;
+    return WFPT_OK;
+}
+
+int render_one(wfpt_ctx *c) {
+    WFPT_HIP(c, hipSetDevice(c->device));
+    if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
+    if (c->p.flags & WFPT_FLAG_NO_GRAPH) {
+        if (int r = enqueue_sample(c, nullptr); r != WFPT_OK) return r;
+    } else {
+        if (!c->graph_exec) {
+            WFPT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int r = enqueue_sample(c, nullptr);
+            const hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+            if (r != WFPT_OK) return r;
+            if (e != hipSuccess) return hip_fail(c, e, "hipStreamEndCapture");
+            WFPT_HIP(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        }
+        WFPT_HIP(c, hipGraphLaunch(c->graph_exec, c->stream));
+    }
+    c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
+    c->progress_frame += 1;      // the device advanced ctl->frame.frame itself
+    c->accumulated_samples += 1; // pt:363
+    return WFPT_OK;
+}
+
+int stage_begin(wfpt_ctx *c, int stage) {
+    StageTimer &t = c->timers[stage];
+    if (!t.start) {
+        WFPT_HIP(c, hipEventCreate(&t.start));
+        WFPT_HIP(c, hipEventCreate(&t.stop));
+    }
+    WFPT_HIP(c, hipEventRecord(t.start, c->stream));
+    return WFPT_OK;
+}
+int stage_end(wfpt_ctx *c, int stage) {
+    StageTimer &t = c->timers[stage];
+    WFPT_HIP(c, hipEventRecord(t.stop, c->stream));
+    t.pending = true;
+    return WFPT_OK;
+}
+
+// Rebuilds the reference-order queue from the segment-compacted one: segment c's entries go to
+// positions [base[c], base[c] + count[c]).
+template <typename Emit>
+int walk_segments(wfpt_ctx *c, bool hits, uint32_t n, Emit emit) {
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    Control ctl;
+    WFPT_HIP(c, hipMemcpy(&ctl, c->ctl, sizeof ctl, hipMemcpyDeviceToHost));
+    const uint32_t n_chunks = (ctl.seg_n + kChunk - 1) / kChunk;
+    const uint32_t total = hits ? ctl.hits : ctl.misses;
+    if (n > total) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "read queue: n exceeds the entries the last extend produced");
+    std::vector<uint32_t> count(n_chunks), base(n_chunks);
+    if (n_chunks) {
+        WFPT_HIP(c, hipMemcpy(count.data(), hits ? c->chunk_hits : c->chunk_miss, sizeof(uint32_t) * n_chunks, hipMemcpyDeviceToHost));
+        WFPT_HIP(c, hipMemcpy(base.data(), hits ? c->chunk_hit_base : c->chunk_miss_base, sizeof(uint32_t) * n_chunks, hipMemcpyDeviceToHost));
+    }
+    const size_t span = static_cast<size_t>(n_chunks) * kChunk;
+    std::vector<uint32_t> ridx(span), prim;
+    std::vector<float> t;
+    if (span) {
+        WFPT_HIP(c, hipMemcpy(ridx.data(), hits ? c->hit_ridx : c->miss_ridx, sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
+        if (hits) {
+            prim.resize(span);
+            t.resize(span);
+            WFPT_HIP(c, hipMemcpy(prim.data(), c->hit_prim, sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
+            WFPT_HIP(c, hipMemcpy(t.data(), c->hit_t, sizeof(float) * span, hipMemcpyDeviceToHost));
+        }
+    }
+    for (uint32_t ch = 0; ch < n_chunks; ++ch)
+        for (uint32_t r = 0; r < count[ch]; ++r) {
+            const uint32_t pos = base[ch] + r;
+            if (pos >= n) continue;
+            const size_t slot = static_cast<size_t>(ch) * kChunk + r;
+            emit(pos, ridx[slot], hits ? t[slot] : 0.0f, hits ? prim[slot] : 0u);
+        }
+    return WFPT_OK;
+}
+
+
+} // namespace
+
+extern "C" {
+
+const char *wfpt_build_info(void) {
+    static const std::string info = std::string("arch=gfx950;chunk=") + std::to_string(kChunk) +
+                                    ";extend_threads=" + std::to_string(kExtendThreads) + ";fp=ieee-no-contract";
+    return info.c_str();
+}
+
+int wfpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *wfpt_last_error(const wfpt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uint32_t n_spheres,
+                      const wfpt_material *materials, uint32_t n_materials, const wfpt_bvh_node *nodes,
+                      uint32_t n_nodes, const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]) {
+    if (!params || !spheres || !materials || !nodes || !camera || !inv_proj || !view || n_spheres == 0 ||
+        n_materials == 0 || params->width == 0 || params->height == 0) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: null or empty argument");
+        return nullptr;
+    }
+    if (params->max_wavefronts == 0 || params->max_wavefronts > static_cast<uint32_t>(kMaxRows)) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: max_wavefronts must be in 1..64");
+        return nullptr;
+    }
+    if (static_cast<uint64_t>(params->width) * params->height > (1ull << 31)) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: image too large");
+        return nullptr;
+    }
+    for (uint32_t i = 0; i < n_spheres; ++i)
+        if (spheres[i].material_idx >= n_materials) {
+            fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: sphere material_idx out of range");
+            return nullptr;
+        }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0 || params->device < 0 || params->device >= n_dev) {
+        fail(nullptr, WFPT_ERR_NO_DEVICE, "wfpt_create: no HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    auto *c = new wfpt_ctx();
+    c->p = *params;
+    c->device = params->device;
+    c->tile.world = params->tile_world == 0 ? 1u : params->tile_world;
+    c->tile.rank = params->tile_world == 0 ? 0u : params->tile_rank;
+    if (c->tile.rank >= c->tile.world) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: tile_rank >= tile_world");
+        delete c;
+        return nullptr;
+    }
+    std::vector<uint16_t> pair_parent;
+    if (validate_bvh(c, nodes, n_nodes, n_spheres, pair_parent) < 0) {
+        g_last_error = c->err;
+        delete c;
+        return nullptr;
+    }
+    auto bail = [&](hipError_t e, const char *what) -> wfpt_ctx * {
+        hip_fail(c, e, what);
+        g_last_error = c->err;
+        wfpt_destroy(c);
+        return nullptr;
+    };
+#define CREATE_HIP(call)                                  \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return bail(e_, #call);     \
+    } while (0)
+
+    CREATE_HIP(hipSetDevice(c->device));
+    CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    set_viewport(c, params->width, params->height);
+    c->pixel_capacity = std::max(c->n_pixels, c->tile.world <= 1 ? params->max_pixels : 0u);
+    // ray slots: whole tiles (partial tiles carry padding lanes), rounded up to whole segments
+    const uint64_t tile_slots = static_cast<uint64_t>(c->tiles_x) * c->tiles_y_local * 64u;
+    uint64_t cap = std::max<uint64_t>(tile_slots, c->pixel_capacity);
+    if (c->pixel_capacity > c->n_pixels) cap += 16ull * (static_cast<uint64_t>(c->pixel_capacity) / 8u + 64u) ; // room for partial tiles after a resize
+    cap = (cap + kChunk - 1) / kChunk * kChunk;
+    if (cap == 0) cap = kChunk;
+    c->capacity = static_cast<uint32_t>(cap);
+    c->n_chunks_max = c->capacity / kChunk;
+
+    for (int k = 0; k < 2; ++k) {
+        CREATE_HIP(dmalloc(&c->ray_mem[k], 7 * static_cast<size_t>(c->capacity)));
+        CREATE_HIP(hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * 7 * static_cast<size_t>(c->capacity), c->stream));
+        set_queue(c->q[k], c->ray_mem[k], c->capacity);
+    }
+    CREATE_HIP(dmalloc(&c->hit_t, c->capacity));
+    CREATE_HIP(dmalloc(&c->hit_prim, c->capacity));
+    CREATE_HIP(dmalloc(&c->hit_ridx, c->capacity));
+    CREATE_HIP(dmalloc(&c->miss_ridx, c->capacity));
+    CREATE_HIP(dmalloc(&c->chunk_hits, c->n_chunks_max));
+    CREATE_HIP(dmalloc(&c->chunk_miss, c->n_chunks_max));
+    CREATE_HIP(dmalloc(&c->chunk_hit_base, c->n_chunks_max));
+    CREATE_HIP(dmalloc(&c->chunk_miss_base, c->n_chunks_max));
+    CREATE_HIP(hipMemsetAsync(c->chunk_hits, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
+    CREATE_HIP(hipMemsetAsync(c->chunk_miss, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
+    CREATE_HIP(hipMemsetAsync(c->chunk_hit_base, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
+    CREATE_HIP(hipMemsetAsync(c->chunk_miss_base, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
+    const size_t img_floats = 3 * static_cast<size_t>(c->pixel_capacity) + 4;
+    CREATE_HIP(dmalloc(&c->image, img_floats));
+    CREATE_HIP(dmalloc(&c->accumulated, img_floats));
+    CREATE_HIP(launch_fill(c->image, 1.0f, img_floats, c->stream));                           // pt:53-58
+    CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * img_floats, c->stream));     // pt:60-65
+    CREATE_HIP(dmalloc(&c->ctl, 1));
+    CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control), c->stream));
+    CREATE_HIP(dmalloc(&c->camera, 1));
+
+    // scene upload (pt:120-128) plus the traversal's LDS-friendly copies
+    c->h_spheres.assign(spheres, spheres + n_spheres);
+    std::vector<float4> geom(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; ++i)
+        geom[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
+    CREATE_HIP(dmalloc(&c->d_nodes, n_nodes));
+    CREATE_HIP(dmalloc(&c->d_sphere_geom, n_spheres));
+    CREATE_HIP(dmalloc(&c->d_pair_parent, pair_parent.size()));
+    CREATE_HIP(dmalloc(&c->d_spheres, n_spheres));
+    CREATE_HIP(dmalloc(&c->d_materials, n_materials));
+    CREATE_HIP(hipMemcpy(c->d_nodes, nodes, sizeof(wfpt_bvh_node) * n_nodes, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(c->d_sphere_geom, geom.data(), sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(c->d_pair_parent, pair_parent.data(), sizeof(uint16_t) * pair_parent.size(), hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(c->d_spheres, spheres, sizeof(wfpt_sphere) * n_spheres, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(c->d_materials, materials, sizeof(wfpt_material) * n_materials, hipMemcpyHostToDevice));
+    c->scene.nodes = c->d_nodes;
+    c->scene.sphere_geom = c->d_sphere_geom;
+    c->scene.pair_parent = c->d_pair_parent;
+    c->scene.spheres = c->d_spheres;
+    c->scene.materials = c->d_materials;
+    c->scene.n_nodes = n_nodes;
+    c->scene.n_spheres = n_spheres;
+    c->scene.n_materials = n_materials;
+    c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres);
+    if (c->scene.lds_bytes > 160u * 1024u) {
+        fail(c, WFPT_ERR_UNSUPPORTED, "scene does not fit the 160 KiB LDS of a gfx950 CU");
+        g_last_error = c->err;
+        wfpt_destroy(c);
+        return nullptr;
+    }
+
+    CameraDev cam{};
+    cam.cam = *camera;
+    std::memcpy(cam.inv_proj, inv_proj, sizeof cam.inv_proj);
+    std::memcpy(cam.view, view, sizeof cam.view);
+    CREATE_HIP(hipMemcpy(c->camera, &cam, sizeof cam, hipMemcpyHostToDevice));
+    const wfpt_frame_buffer f{c->width, c->height, 0u, 0u};
+    CREATE_HIP(hipMemcpy(&c->ctl->frame, &f, sizeof f, hipMemcpyHostToDevice));
+
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
+    int blocks_per_cu = 1;
+    CREATE_HIP(extend_blocks_per_cu(c->scene.lds_bytes, &blocks_per_cu));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const uint32_t cus = static_cast<uint32_t>(prop.multiProcessorCount);
+    c->extend_grid = std::min(c->n_chunks_max, cus * static_cast<uint32_t>(blocks_per_cu));
+    c->consumer_grid = std::min(c->n_chunks_max, cus * 8u);
+    c->accumulate_grid = std::min<uint32_t>((3u * c->pixel_capacity / 4u + 255u) / 256u, cus * 8u);
+    if (c->accumulate_grid == 0) c->accumulate_grid = 1;
+    CREATE_HIP(hipStreamSynchronize(c->stream));
+#undef CREATE_HIP
+    return c;
+}
+
+void wfpt_destroy(wfpt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    destroy_graph(c);
+    for (auto &t : c->timers) {
+        if (t.start) (void)hipEventDestroy(t.start);
+        if (t.stop) (void)hipEventDestroy(t.stop);
+    }
+    for (auto e : c->sample_events) (void)hipEventDestroy(e);
+    void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_t, c->hit_prim, c->hit_ridx, c->miss_ridx, c->chunk_hits,
+                    c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->image, c->accumulated, c->ctl, c->camera,
+                    c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_spheres, c->d_materials};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int wfpt_set_frame(wfpt_ctx *c, const wfpt_frame_buffer *frame) {
+    if (!c || !frame) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_set_frame: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipMemcpyAsync(&c->ctl->frame, frame, sizeof *frame, hipMemcpyHostToDevice, c->stream));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    c->dev_frame_valid = false;
+    return WFPT_OK;
+}
+
+int wfpt_update_render_parameters(wfpt_ctx *c, uint32_t width, uint32_t height, const wfpt_gpu_camera *camera,
+                                  const float inv_proj[16], const float view[16]) {
+    if (!c || !camera || !inv_proj || !view || width == 0 || height == 0)
+        return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_render_parameters: null or empty argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    wfpt_ctx probe;
+    probe.tile = c->tile;
+    set_viewport(&probe, width, height);
+    const uint64_t slots = static_cast<uint64_t>(probe.tiles_x) * probe.tiles_y_local * 64u;
+    if (probe.n_pixels > c->pixel_capacity || slots > c->capacity)
+        return fail(c, WFPT_ERR_INVALID_ARGUMENT, "viewport exceeds the capacity given at wfpt_create (max_pixels)");
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    set_viewport(c, width, height);
+    CameraDev cam{};
+    cam.cam = *camera;
+    std::memcpy(cam.inv_proj, inv_proj, sizeof cam.inv_proj);
+    std::memcpy(cam.view, view, sizeof cam.view);
+    WFPT_HIP(c, hipMemcpy(c->camera, &cam, sizeof cam, hipMemcpyHostToDevice));       // pt:259-272
+    WFPT_HIP(c, hipMemsetAsync(c->accumulated, 0, sizeof(float) * 3 * static_cast<size_t>(c->pixel_capacity), c->stream)); // pt:248-250
+    c->progress_frame = 0;      // RenderProgress::reset, pt:276
+    c->accumulated_samples = 0;
+    c->dev_frame_valid = false;
+    destroy_graph(c); // grid shapes are baked into the captured graph
+    return WFPT_OK;
+}
+
+int wfpt_set_counters(wfpt_ctx *c, const uint32_t counters[16]) {
+    if (!c || !counters) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_set_counters: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipMemcpyAsync(c->ctl->counters, counters, sizeof(uint32_t) * 16, hipMemcpyHostToDevice, c->stream));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    return WFPT_OK;
+}
+
+int wfpt_read_counters(wfpt_ctx *c, uint32_t counters[16]) {
+    if (!c || !counters) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_counters: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, hipMemcpy(counters, c->ctl->counters, sizeof(uint32_t) * 16, hipMemcpyDeviceToHost));
+    return WFPT_OK;
+}
+
+int wfpt_reset_image(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, launch_fill(c->image, 1.0f, 3 * static_cast<size_t>(c->pixel_capacity), c->stream));
+    return WFPT_OK;
+}
+
+int wfpt_reset_accumulated(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipMemsetAsync(c->accumulated, 0, sizeof(float) * 3 * static_cast<size_t>(c->pixel_capacity), c->stream));
+    return WFPT_OK;
+}
+
+int wfpt_clear_ray_queues(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    for (int k = 0; k < 2; ++k)
+        WFPT_HIP(c, hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * 7 * static_cast<size_t>(c->capacity), c->stream));
+    return WFPT_OK;
+}
+
+int wfpt_swap_ray_queues(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    c->cur ^= 1;
+    return WFPT_OK;
+}
+
+int wfpt_kernel_run(wfpt_ctx *c, int stage, uint32_t gx, uint32_t gy) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    if (stage < 0 || stage >= WFPT_STAGE_SCAN) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_kernel_run: unknown stage");
+    const uint64_t threads64 = static_cast<uint64_t>(gx) * gy * 64u;
+    if (threads64 == 0) return WFPT_OK; // an empty dispatch
+    const uint32_t threads = threads64 > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(threads64);
+    WFPT_HIP(c, hipSetDevice(c->device));
+    if (int r = stage_begin(c, stage); r != WFPT_OK) return r;
+    switch (stage) {
+    case WFPT_STAGE_GENERATE_RAYS:
+        if (threads64 > c->capacity)
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch exceeds the ray buffer (max_pixels)");
+        if (static_cast<uint64_t>(gx) * 8u * gy * 8u * (c->tile.world) > (1ull << 32))
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch too large");
+        WFPT_HIP(c, launch_generate(generate_args(c, gx, gy, false), c->stream));
+        break;
+    case WFPT_STAGE_EXTEND:
+        WFPT_HIP(c, launch_extend(extend_args(c, c->cur, &c->ctl->counters[2], threads), c->extend_grid, c->stream));
+        WFPT_HIP(c, launch_scan(scan_args(c, &c->ctl->counters[2], threads, false, 0), c->stream));
+        break;
+    case WFPT_STAGE_SHADE:
+        WFPT_HIP(c, launch_shade(shade_args(c, c->cur, &c->ctl->counters[1], threads, gx, 0xffffffffu, true),
+                                 c->consumer_grid, c->stream));
+        break;
+    case WFPT_STAGE_SHADE_LAMBERTIAN:
+    case WFPT_STAGE_SHADE_METAL:
+    case WFPT_STAGE_SHADE_DIELECTRIC:
+        WFPT_HIP(c, launch_shade(shade_args(c, c->cur, &c->ctl->counters[1], threads, gx,
+                                            static_cast<uint32_t>(stage - WFPT_STAGE_SHADE_LAMBERTIAN), true),
+                                 c->consumer_grid, c->stream));
+        break;
+    case WFPT_STAGE_MISS:
+        WFPT_HIP(c, launch_miss(miss_args(c, c->cur, &c->ctl->counters[0], threads), c->consumer_grid, c->stream));
+        break;
+    case WFPT_STAGE_ACCUMULATE:
+        WFPT_HIP(c, launch_accumulate(accumulate_args(c, threads, false), c->accumulate_grid, c->stream));
+        break;
+    default: break;
+    }
+    return stage_end(c, stage);
+}
+
+float wfpt_kernel_timing_us(wfpt_ctx *c, int stage) {
+    if (!c || stage < 0 || stage >= WFPT_STAGE_COUNT) return 0.0f;
+    StageTimer &t = c->timers[stage];
+    if (t.pending) {
+        (void)hipSetDevice(c->device);
+        if (hipEventSynchronize(t.stop) == hipSuccess) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+                if (t.window.size() == 10) t.window.pop_back(); // query_gpu.rs:33-38
+                t.window.push_front(static_cast<double>(ms) * 1000.0);
+            }
+        }
+        t.pending = false;
+    }
+    if (t.window.empty()) return 0.0f;
+    double sum = 0.0;
+    for (double v : t.window) sum += v;
+    return static_cast<float>(sum / static_cast<double>(t.window.size()));
+}
+
+int wfpt_render_sample(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    return render_one(c);
+}
+
+int wfpt_render(wfpt_ctx *c, uint32_t n_samples) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    for (uint32_t s = 0; s < n_samples; ++s)
+        if (int r = render_one(c); r != WFPT_OK) return r;
+    return WFPT_OK;
+}
+
+int wfpt_render_sample_timed(wfpt_ctx *c, float *stage_ms, uint32_t *stage_launches) {
+    if (!c || !stage_ms) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_sample_timed: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
+    std::vector<EventRec> ev;
+    if (int r = enqueue_sample(c, &ev); r != WFPT_OK) return r;
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    for (const EventRec &e : ev) {
+        float ms = 0.0f;
+        WFPT_HIP(c, hipEventElapsedTime(&ms, e.start, e.stop));
+        stage_ms[e.stage] += ms;
+        if (stage_launches) stage_launches[e.stage] += 1;
+    }
+    c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
+    c->progress_frame += 1;
+    c->accumulated_samples += 1;
+    return WFPT_OK;
+}
+
+int wfpt_synchronize(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    return WFPT_OK;
+}
+
+uint32_t wfpt_frame(const wfpt_ctx *c) { return c ? c->progress_frame : 0; }
+uint32_t wfpt_accumulated_samples(const wfpt_ctx *c) { return c ? c->accumulated_samples : 0; }
+float wfpt_progress(const wfpt_ctx *c, uint32_t spp) {
+    return (c && spp) ? static_cast<float>(c->accumulated_samples) / static_cast<float>(spp) : 0.0f;
+}
+uint32_t wfpt_n_pixels(const wfpt_ctx *c) { return c ? c->n_pixels : 0; }
+uint32_t wfpt_ray_capacity(const wfpt_ctx *c) { return c ? c->capacity : 0; }
+
+int wfpt_read_accumulated(wfpt_ctx *c, float *rgb, size_t n_floats) {
+    if (!c || !rgb) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_accumulated: null argument");
+    if (n_floats > 3 * static_cast<size_t>(c->n_pixels)) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "n_floats exceeds the image");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, hipMemcpy(rgb, c->accumulated, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+    return WFPT_OK;
+}
+
+int wfpt_read_image(wfpt_ctx *c, float *rgb, size_t n_floats) {
+    if (!c || !rgb) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_image: null argument");
+    if (n_floats > 3 * static_cast<size_t>(c->n_pixels)) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "n_floats exceeds the image");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, hipMemcpy(rgb, c->image, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+    return WFPT_OK;
+}
+
+int wfpt_copy_accumulated_to_device(wfpt_ctx *c, void *device_ptr, size_t n_bytes) {
+    if (!c || !device_ptr) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_copy_accumulated_to_device: null argument");
+    if (n_bytes > sizeof(float) * 3 * static_cast<size_t>(c->n_pixels))
+        return fail(c, WFPT_ERR_INVALID_ARGUMENT, "n_bytes exceeds the image");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipMemcpyAsync(device_ptr, c->accumulated, n_bytes, hipMemcpyDeviceToDevice, c->stream));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    return WFPT_OK;
+}
+
+static int read_ray_queue(wfpt_ctx *c, int qi, wfpt_ray *rays, uint32_t n) {
+    if (!c || !rays) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "read rays: null argument");
+    if (n > c->capacity) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "read rays: n exceeds the queue capacity");
+    if (n == 0) return WFPT_OK;
+    WFPT_HIP(c, hipSetDevice(c->device));
+    wfpt_ray *tmp = nullptr;
+    WFPT_HIP(c, dmalloc(&tmp, n));
+    hipError_t e = launch_rays_to_aos(c->q[qi], tmp, n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(rays, tmp, sizeof(wfpt_ray) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(c, e, "read rays");
+    return WFPT_OK;
+}
+
+int wfpt_read_rays(wfpt_ctx *c, wfpt_ray *rays, uint32_t n) { return read_ray_queue(c, c ? c->cur : 0, rays, n); }
+int wfpt_read_extension_rays(wfpt_ctx *c, wfpt_ray *rays, uint32_t n) {
+    return read_ray_queue(c, c ? (c->cur ^ 1) : 0, rays, n);
+}
+
+int wfpt_write_rays(wfpt_ctx *c, const wfpt_ray *rays, uint32_t n) {
+    if (!c || !rays) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: null argument");
+    if (n > c->capacity) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: n exceeds the queue capacity");
+    if (n == 0) return WFPT_OK;
+    WFPT_HIP(c, hipSetDevice(c->device));
+    wfpt_ray *tmp = nullptr;
+    WFPT_HIP(c, dmalloc(&tmp, n));
+    hipError_t e = hipMemcpy(tmp, rays, sizeof(wfpt_ray) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_rays_from_aos(c->q[c->cur], tmp, n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(c, e, "wfpt_write_rays");
+    return WFPT_OK;
+}
+
+int wfpt_read_hits(wfpt_ctx *c, wfpt_hit_payload *out, uint32_t n) {
+    if (!c || !out) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_hits: null argument");
+    return walk_segments(c, true, n, [&](uint32_t pos, uint32_t ridx, float t, uint32_t prim) {
+        out[pos].t = t;
+        out[pos].ray_idx = ridx;
+        out[pos].sphere_idx = prim;
+        out[pos].mat_type = prim < c->h_spheres.size() ? c->h_spheres[prim].material_type : 0u; // ex:199
+    });
+}
+
+int wfpt_read_misses(wfpt_ctx *c, uint32_t *out, uint32_t n) {
+    if (!c || !out) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_misses: null argument");
+    return walk_segments(c, false, n, [&](uint32_t pos, uint32_t ridx, float, uint32_t) { out[pos] = ridx; });
+}
+
+int wfpt_read_bounce_table(wfpt_ctx *c, uint32_t *rows4, uint32_t max_rows, uint32_t *n_rows) {
+    if (!c || !rows4 || !n_rows) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_bounce_table: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    Control ctl;
+    WFPT_HIP(c, hipMemcpy(&ctl, c->ctl, sizeof ctl, hipMemcpyDeviceToHost));
+    // rows of wavefronts whose extend really ran (the device keeps writing empty rows after the loop exits)
+    uint32_t n = 0;
+    const uint32_t rows = std::min<uint32_t>(ctl.bounce, kMaxRows);
+    for (uint32_t b = 0; b < rows && n < max_rows; ++b) {
+        if (ctl.rows[b][0] == 0) break;
+        std::memcpy(rows4 + 4 * n, ctl.rows[b], sizeof(uint32_t) * 4);
+        ++n;
+    }
+    *n_rows = n;
+    return WFPT_OK;
+}
+
+int wfpt_read_totals(wfpt_ctx *c, uint64_t totals[3]) {
+    if (!c || !totals) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_totals: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    Control ctl;
+    WFPT_HIP(c, hipMemcpy(&ctl, c->ctl, sizeof ctl, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) totals[k] = ctl.totals[k];
+    return WFPT_OK;
+}
+
+int wfpt_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n) {
+    if (!a || !out) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_selftest_math: null argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return fail(nullptr, WFPT_ERR_NO_DEVICE, "wfpt_selftest_math: no HIP device");
+    WFPT_HIP(nullptr, hipSetDevice(device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    hipError_t e = dmalloc(&da, n);
+    if (e == hipSuccess) e = dmalloc(&dout, n);
+    if (e == hipSuccess && b) e = dmalloc(&db, n);
+    if (e == hipSuccess) e = hipMemcpy(da, a, sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(db, b, sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_selftest_math(op, da, db, dout, n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost);
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "wfpt_selftest_math");
+    return WFPT_OK;
+}
+
+} // extern "C"

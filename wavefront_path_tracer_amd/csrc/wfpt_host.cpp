@@ -1,0 +1,354 @@
+// wfpt_host.cpp -- host-side data model of the path: scene generators, BVH builder, camera and
+// projection set-up, dispatch sizing. C++ restatement of wavefront_common (Rust) so that a host
+// without the crate can produce byte-identical inputs for the kernel chain. No GPU code here.
+//
+// Build with -ffp-contract=off: every expression below is evaluated in plain IEEE binary32, in the
+// association order the Rust/glam source uses, so results are reproducible across compilers.
+// Citations are relative to the reference root (wc = wavefront_common/src).
+#include "wfpt.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+struct Vec3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 vmin(Vec3 a, Vec3 b) { return {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}; }
+inline Vec3 vmax(Vec3 a, Vec3 b) { return {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}; }
+inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } // glam Vec3::dot
+inline float length(Vec3 a) { return std::sqrt(dot(a, a)); }
+// glam Vec3::cross
+inline Vec3 cross(Vec3 a, Vec3 b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+// ---- seeded stand-in for rand::thread_rng (wc/util_funcs.rs:6-30): PCG32 XSH-RR, stream 54 ----
+class SceneRng {
+  public:
+    explicit SceneRng(uint64_t seed) : state_(0), inc_((54ULL << 1) | 1ULL) {
+        next_u32();
+        state_ += seed;
+        next_u32();
+    }
+    uint32_t next_u32() {
+        const uint64_t old = state_;
+        state_ = old * 6364136223846793005ULL + inc_;
+        const uint32_t xs = static_cast<uint32_t>(((old >> 18) ^ old) >> 27);
+        const uint32_t rot = static_cast<uint32_t>(old >> 59);
+        return (xs >> rot) | (xs << ((32u - rot) & 31u));
+    }
+    float f32() { return static_cast<float>(next_u32() >> 8) * (1.0f / 16777216.0f); } // random_f32
+    float range(float lo, float hi) { return lo + (hi - lo) * f32(); }                  // random_range_f32
+  private:
+    uint64_t state_, inc_;
+};
+
+wfpt_sphere make_sphere(Vec3 c, float r, uint32_t mat_idx, uint32_t mat_type) { // wc/sphere.rs:18-20
+    wfpt_sphere s;
+    s.center[0] = c.x; s.center[1] = c.y; s.center[2] = c.z; s.center[3] = 1.0f;
+    s.radius = r; s.material_idx = mat_idx; s.material_type = mat_type; s._buffer = 0;
+    return s;
+}
+wfpt_material make_material(Vec3 albedo, float fuzz, float ri, uint32_t type) {
+    wfpt_material m;
+    m.albedo[0] = albedo.x; m.albedo[1] = albedo.y; m.albedo[2] = albedo.z; m.albedo[3] = 1.0f;
+    m.fuzz = fuzz; m.refract_index = ri; m.material_type = type; m._buffer = 0;
+    return m;
+}
+wfpt_material lambertian(Vec3 a) { return make_material(a, 0.0f, 0.0f, 0); }            // material.rs:26-28
+wfpt_material metal(Vec3 a, float fuzz) {                                                 // material.rs:30-32
+    return make_material(a, fuzz < 0.0f ? 0.0f : (fuzz > 1.0f ? 1.0f : fuzz), 0.0f, 1);
+}
+wfpt_material dielectric(float ri) { return make_material({1.0f, 1.0f, 1.0f}, 0.0f, ri, 2); } // material.rs:34-36
+
+// ---- BVH builder (wc/bvh.rs) ----
+constexpr int kBins = 4096; // bvh.rs:4
+
+struct Aabb {
+    Vec3 lo{kInf, kInf, kInf}, hi{-kInf, -kInf, -kInf};
+    void grow(Vec3 a, Vec3 b) { lo = vmin(lo, a); hi = vmax(hi, b); }
+    float half_area() const { // Bin::get_area, bvh.rs:29-35
+        if (!(std::isfinite(hi.x) && std::isfinite(hi.y) && std::isfinite(hi.z))) return 0.0f;
+        const Vec3 e = hi - lo;
+        return (e.x * e.y + e.y * e.z) + e.z * e.x;
+    }
+};
+
+inline void sphere_bounds(const wfpt_sphere &s, Vec3 &lo, Vec3 &hi) { // sphere.rs:22-26
+    lo = {s.center[0] - s.radius, s.center[1] - s.radius, s.center[2] - s.radius};
+    hi = {s.center[0] + s.radius, s.center[1] + s.radius, s.center[2] + s.radius};
+}
+
+class BvhBuilder {
+  public:
+    BvhBuilder(wfpt_sphere *spheres, wfpt_bvh_node *nodes) : spheres_(spheres), nodes_(nodes) {
+        bins_.resize(kBins);
+        bin_count_.resize(kBins);
+        left_count_.resize(kBins - 1);
+        right_count_.resize(kBins - 1);
+        left_area_.resize(kBins - 1);
+        right_area_.resize(kBins - 1);
+    }
+
+    uint32_t build(uint32_t n) { // bvh.rs:152-164
+        wfpt_bvh_node root{};
+        root.left_first = 0;
+        root.prim_count = n;
+        fit(root);
+        nodes_[count_++] = root;
+        nodes_[count_++] = wfpt_bvh_node{}; // bvh.rs:160-161 placeholder so siblings sit at (2k, 2k+1)
+        subdivide(0);
+        return count_;
+    }
+
+  private:
+    void fit(wfpt_bvh_node &nd) const { // update_node_bounds, bvh.rs:58-70
+        Aabb box;
+        for (uint32_t i = 0; i < nd.prim_count; ++i) {
+            Vec3 lo, hi;
+            sphere_bounds(spheres_[nd.left_first + i], lo, hi);
+            box.grow(lo, hi);
+        }
+        nd.aabb_min[0] = box.lo.x; nd.aabb_min[1] = box.lo.y; nd.aabb_min[2] = box.lo.z;
+        nd.aabb_max[0] = box.hi.x; nd.aabb_max[1] = box.hi.y; nd.aabb_max[2] = box.hi.z;
+    }
+
+    struct Split { float cost; int axis; float plane; };
+
+    Split best_split(const wfpt_bvh_node &nd) { // find_best_split_plane, bvh.rs:73-139
+        const float extent[3] = {nd.aabb_max[0] - nd.aabb_min[0], nd.aabb_max[1] - nd.aabb_min[1],
+                                 nd.aabb_max[2] - nd.aabb_min[2]};
+        Split best{kInf, 0, 0.0f};
+        for (int axis = 0; axis < 3; ++axis) {
+            if (extent[axis] < 0.00001f) continue;
+            for (int b = 0; b < kBins; ++b) { bins_[b] = Aabb{}; bin_count_[b] = 0; }
+            const float scale = static_cast<float>(kBins) / extent[axis];
+            const float lo_bound = nd.aabb_min[axis];
+            for (uint32_t i = 0; i < nd.prim_count; ++i) {
+                const wfpt_sphere &s = spheres_[nd.left_first + i];
+                const float pos = (s.center[axis] - lo_bound) * scale;
+                // Rust `as usize` saturates (negative/NaN -> 0), then .min(BINS - 1)
+                long long b = pos > 0.0f ? (pos >= 2147483648.0f ? 2147483647LL : static_cast<long long>(pos)) : 0;
+                if (b > kBins - 1) b = kBins - 1;
+                Vec3 lo, hi;
+                sphere_bounds(s, lo, hi);
+                bins_[b].grow(lo, hi);
+                bin_count_[b] += 1;
+            }
+            // prefix sweeps from both ends; N bins -> N-1 candidate planes
+            Aabb left, right;
+            uint32_t nl = 0, nr = 0;
+            for (int i = 0; i < kBins - 1; ++i) {
+                nl += bin_count_[i];
+                left_count_[i] = nl;
+                left.grow(bins_[i].lo, bins_[i].hi);
+                left_area_[i] = left.half_area();
+                nr += bin_count_[kBins - 1 - i];
+                right_count_[kBins - 2 - i] = nr;
+                right.grow(bins_[kBins - 1 - i].lo, bins_[kBins - 1 - i].hi);
+                right_area_[kBins - 2 - i] = right.half_area();
+            }
+            const float step = 1.0f / static_cast<float>(kBins);
+            for (int i = 0; i < kBins - 1; ++i) {
+                const float cost = static_cast<float>(left_count_[i]) * left_area_[i] +
+                                   static_cast<float>(right_count_[i]) * right_area_[i];
+                if (cost < best.cost) {
+                    best.cost = cost;
+                    best.axis = axis;
+                    best.plane = lo_bound + extent[axis] * step * (1.0f + static_cast<float>(i));
+                }
+            }
+        }
+        return best;
+    }
+
+    void subdivide(uint32_t index) { // bvh.rs:166-210
+        const Split split = best_split(nodes_[index]);
+        const float ex = nodes_[index].aabb_max[0] - nodes_[index].aabb_min[0];
+        const float ey = nodes_[index].aabb_max[1] - nodes_[index].aabb_min[1];
+        const float ez = nodes_[index].aabb_max[2] - nodes_[index].aabb_min[2];
+        const float leaf_cost = static_cast<float>(nodes_[index].prim_count) * ((ex * ey + ey * ez) + ez * ex);
+        if (leaf_cost <= split.cost) return;
+
+        // in-place partition; signed cursors (the reference's usize `j -= 1` can underflow)
+        long long i = nodes_[index].left_first;
+        long long j = i + static_cast<long long>(nodes_[index].prim_count) - 1;
+        while (i <= j) {
+            if (spheres_[i].center[split.axis] < split.plane) {
+                ++i;
+            } else {
+                std::swap(spheres_[i], spheres_[j]);
+                --j;
+            }
+        }
+        const uint32_t n_left = static_cast<uint32_t>(i) - nodes_[index].left_first;
+        if (n_left == 0 || n_left == nodes_[index].prim_count) return;
+
+        const uint32_t child = count_;
+        wfpt_bvh_node l{}, r{};
+        l.left_first = nodes_[index].left_first;
+        l.prim_count = n_left;
+        fit(l);
+        r.left_first = static_cast<uint32_t>(i);
+        r.prim_count = nodes_[index].prim_count - n_left;
+        fit(r);
+        nodes_[index].left_first = child;
+        nodes_[index].prim_count = 0;
+        nodes_[count_++] = l;
+        nodes_[count_++] = r;
+        subdivide(child);
+        subdivide(child + 1);
+    }
+
+    wfpt_sphere *spheres_;
+    wfpt_bvh_node *nodes_;
+    uint32_t count_ = 0;
+    std::vector<Aabb> bins_;
+    std::vector<uint32_t> bin_count_, left_count_, right_count_;
+    std::vector<float> left_area_, right_area_;
+};
+
+const char *const kStageNames[WFPT_STAGE_COUNT] = {"generate_rays",    "extend",      "shade",           "miss_kernel",
+                                                   "accumulate",       "shade_lambertian", "shade_metal", "shade_dielectric",
+                                                   "scan"};
+
+} // namespace
+
+extern "C" {
+
+uint32_t wfpt_scene_new(wfpt_sphere *sp, wfpt_material *mt) { // scene.rs:12-46
+    mt[0] = lambertian({0.8f, 0.8f, 0.0f});
+    mt[1] = lambertian({0.1f, 0.2f, 0.5f});
+    mt[2] = dielectric(1.50f);
+    mt[3] = metal({0.8f, 0.6f, 0.2f}, 1.0f);
+    mt[4] = dielectric(1.00f / 1.50f);
+    // vec![ground, center, right, left, bubble]
+    sp[0] = make_sphere({0.0f, -100.5f, -1.0f}, 100.0f, 0, 0);
+    sp[1] = make_sphere({0.0f, 0.0f, -1.2f}, 0.5f, 1, 0);
+    sp[2] = make_sphere({1.0f, 0.0f, -1.0f}, 0.5f, 3, 1);
+    sp[3] = make_sphere({-1.0f, 0.0f, -1.0f}, 0.5f, 2, 2);
+    sp[4] = make_sphere({-1.0f, 0.0f, -1.0f}, 0.4f, 4, 2);
+    return 5;
+}
+
+uint32_t wfpt_scene_book_one_final(uint64_t seed, wfpt_sphere *sp, wfpt_material *mt, uint32_t capacity) {
+    if (capacity < 488) return 0; // 1 ground + 22*22 marbles + 3 big spheres
+    SceneRng rng(seed);
+    uint32_t n = 0;
+    auto push = [&](const wfpt_material &m, Vec3 c, float r) {
+        mt[n] = m;
+        sp[n] = make_sphere(c, r, n, m.material_type); // (materials.len() - 1) as u32
+        ++n;
+    };
+    push(lambertian({0.5f, 0.5f, 0.5f}), {0.0f, -1000.0f, 0.0f}, 1000.0f); // scene.rs:52-59
+    for (int a = -11; a < 11; ++a) {                                          // scene.rs:62-91
+        for (int b = -11; b < 11; ++b) {
+            const float choose_mat = rng.f32();
+            const float cx = static_cast<float>(a) + 0.9f * rng.f32();
+            const float cz = static_cast<float>(b) + 0.9f * rng.f32();
+            const Vec3 center{cx, 0.2f, cz};
+            if (length(center - Vec3{4.0f, 0.2f, 0.0f}) > 0.9f) {
+                if (choose_mat < 0.8f) {
+                    const float r1 = rng.f32(), g1 = rng.f32(), b1 = rng.f32(); // random_vec3() * random_vec3()
+                    const float r2 = rng.f32(), g2 = rng.f32(), b2 = rng.f32();
+                    push(lambertian({r1 * r2, g1 * g2, b1 * b2}), center, 0.2f);
+                } else if (choose_mat < 0.95f) {
+                    const float r = rng.range(0.5f, 1.0f), g = rng.range(0.5f, 1.0f), bl = rng.range(0.5f, 1.0f);
+                    const float fuzz = rng.range(0.0f, 0.5f);
+                    push(metal({r, g, bl}, fuzz), center, 0.2f);
+                } else {
+                    push(dielectric(1.5f), center, 0.2f);
+                }
+            }
+        }
+    }
+    push(dielectric(1.50f), {0.0f, 1.0f, 0.0f}, 1.0f);              // scene.rs:94-96
+    push(lambertian({0.4f, 0.2f, 0.1f}), {-4.0f, 1.0f, 0.0f}, 1.0f); // scene.rs:98-100
+    push(metal({0.7f, 0.6f, 0.5f}, 0.0f), {4.0f, 1.0f, 0.0f}, 1.0f); // scene.rs:102-104
+    return n;
+}
+
+int wfpt_build_bvh(wfpt_sphere *spheres, uint32_t n, wfpt_bvh_node *nodes, uint32_t cap, uint32_t *n_nodes) {
+    if (!spheres || !nodes || !n_nodes || n == 0) return WFPT_ERR_INVALID_ARGUMENT;
+    if (cap < 2 * n) return WFPT_ERR_INVALID_ARGUMENT; // BVHTree::new reserves 2*n (bvh.rs:148-150)
+    BvhBuilder builder(spheres, nodes);
+    *n_nodes = builder.build(n);
+    return WFPT_OK;
+}
+
+void wfpt_camera_new(const float from[3], const float at[3], float *pitch, float *yaw) { // camera.rs:11-24
+    Vec3 f{at[0] - from[0], at[1] - from[1], at[2] - from[2]};
+    const float inv_len = 1.0f / length(f); // glam normalize(): self * length_recip()
+    f = {f.x * inv_len, f.y * inv_len, f.z * inv_len};
+    *pitch = std::acos(f.y);
+    *yaw = std::atan2(f.x, f.z);
+}
+
+void wfpt_view_transform(const float pos[3], float pitch, float yaw, float view[16]) { // camera.rs:41-69
+    const float sp = std::sin(pitch), cp = std::cos(pitch), sy = std::sin(yaw), cy = std::cos(yaw);
+    const Vec3 dir{sp * sy, cp, sp * cy};
+    const Vec3 right = cross(dir, Vec3{0.0f, 1.0f, 0.0f});
+    const Vec3 up = cross(right, dir);
+    const float cols[16] = {right.x, right.y, right.z, 0.0f, up.x,   up.y,   up.z,   0.0f,
+                            dir.x,   dir.y,   dir.z,   0.0f, pos[0], pos[1], pos[2], 1.0f};
+    std::memcpy(view, cols, sizeof cols);
+}
+
+void wfpt_p_inv(float vfov_rad, float aspect, float z_near, float z_far, float out[16]) { // projection_matrix.rs:21-37
+    const float h = std::tan(vfov_rad / 2.0f);
+    const float w = h * aspect;
+    const float r = z_far / (z_far - z_near);
+    const float cols[16] = {w,    0.0f, 0.0f, 0.0f,                    0.0f, h,    0.0f, 0.0f,
+                            0.0f, 0.0f, 0.0f, -1.0f / (r * z_near),   0.0f, 0.0f, 1.0f, 1.0f / z_near};
+    std::memcpy(out, cols, sizeof cols);
+}
+
+void wfpt_gpu_camera_new(const float pos[3], float pitch, float yaw, float defocus_angle_rad, float focus_distance,
+                         wfpt_gpu_camera *out) { // camera_controller.rs:173-185
+    out->position[0] = pos[0]; out->position[1] = pos[1]; out->position[2] = pos[2]; out->position[3] = 1.0f;
+    out->pitch = pitch;
+    out->yaw = yaw;
+    out->defocus_radius = focus_distance * std::tan(0.5f * defocus_angle_rad);
+    out->focus_distance = focus_distance;
+}
+
+float wfpt_to_radians(float deg) { return deg * 0.017453292519943295769236907684886f; }
+
+void wfpt_workgroup_size_64(uint32_t x, uint32_t *gx, uint32_t *gy) { // path_tracer.rs:282-289
+    const uint32_t groups = x / 64u + (x % 64u ? 1u : 0u); // div_ceil
+    if (groups <= 1) { *gx = 1; *gy = 1; return; }         // the reference unwraps None and panics here
+    const uint32_t y = static_cast<uint32_t>(std::ceil(std::sqrt(static_cast<float>(groups))));
+    uint32_t fac = 1;
+    for (uint32_t z = y - 1; z >= 1; --z) { // (1..y).rev().find(|z| groups % z == 0)
+        if (groups % z == 0) { fac = z; break; }
+    }
+    if (groups / fac >= (1u << 16)) { *gx = y; *gy = y; } else { *gx = fac; *gy = groups / fac; }
+}
+
+int wfpt_stage_from_name(const char *name) {
+    if (!name) return -1;
+    for (int s = 0; s < WFPT_STAGE_COUNT; ++s)
+        if (std::strcmp(name, kStageNames[s]) == 0) return s;
+    return -1;
+}
+const char *wfpt_stage_name(int stage) { return (stage >= 0 && stage < WFPT_STAGE_COUNT) ? kStageNames[stage] : ""; }
+
+void wfpt_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb) {
+    // display_shader.wgsl:50-52: color = sqrt(invN * color); the 8-bit target clamps to [0,1]
+    const float inv_n = 1.0f / static_cast<float>(n_samples);
+    for (size_t i = 0; i < 3 * static_cast<size_t>(n_pixels); ++i) {
+        float v = std::sqrt(inv_n * acc[i]);
+        if (!(v > 0.0f)) v = 0.0f;
+        if (v > 1.0f) v = 1.0f;
+        rgb[i] = static_cast<uint8_t>(v * 255.0f + 0.5f);
+    }
+}
+
+} // extern "C"

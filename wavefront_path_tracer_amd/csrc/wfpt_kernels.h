@@ -1,0 +1,165 @@
+// wfpt_kernels.h -- device-side data layout and kernel launchers shared by wfpt_kernels.hip (kernels)
+// and wfpt_api.hip (context, C ABI). Internal; the public surface is include/wfpt.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wfpt.h"
+
+namespace wfpt {
+
+// A ray queue is cut into segments of kChunk consecutive slots. One extend workgroup traces one
+// segment at a time and leaves that segment's hits and misses compacted (stable) at the front of the
+// matching segment of the hit / miss queues; a one-workgroup scan then turns the per-segment counts
+// into global queue positions. See DESIGN.md "Queues".
+constexpr int kChunk = 512;
+constexpr int kExtendThreads = kChunk;
+constexpr int kExtendWaves = kExtendThreads / 64;
+constexpr int kConsumerThreads = 256;
+constexpr int kScanThreads = 1024;
+constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
+constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64
+
+// SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed.
+struct RayQueue {
+    float *ox, *oy, *oz, *dx, *dy, *dz;
+    uint32_t *pixel;
+};
+
+// Hit queue (12 B per hit) and miss queue (4 B per miss), segment-compacted.
+struct HitQueue {
+    float *t;
+    uint32_t *prim;
+    uint32_t *ridx;
+};
+
+// Device-resident control block. `counters` is the reference's counter_buffer (extend.wgsl:41).
+struct Control {
+    uint32_t counters[16];
+    wfpt_frame_buffer frame;
+    uint32_t n_in;       // rays the next fused extend traces
+    uint32_t seg_n;      // rays the last extend traced (segments the consumers walk)
+    uint32_t hits;       // totals of the last extend
+    uint32_t misses;
+    uint32_t shade_n;    // fused loop: hits to shade (0 once the loop has exited)
+    uint32_t miss_n;     // fused loop: misses to shade
+    uint32_t shade_gx;   // x extent of workgroup_size_64(hits): the dispatch shape shade.wgsl:72 keys its RNG on
+    uint32_t done;       // fused loop exited (path_tracer.rs:332)
+    uint32_t ticket;     // extend's dynamic segment ticket
+    uint32_t bounce;     // rows written this sample
+    uint32_t samples;    // fused samples accumulated
+    uint32_t _pad;
+    uint32_t rows[kMaxRows][4]; // (rays_in, hits, misses, shaded) per bounce of the current sample
+    unsigned long long totals[4]; // rays traced, hits, misses, samples
+};
+
+struct SceneDev {
+    const wfpt_bvh_node *nodes;   // reference layout, 32 B
+    const float4 *sphere_geom;    // (cx, cy, cz, r), 16 B
+    const uint16_t *pair_parent;  // parent node of the sibling pair (2k, 2k+1); padded to 8 entries
+    const wfpt_sphere *spheres;   // reference layout (shade reads material_idx / material_type)
+    const wfpt_material *materials;
+    uint32_t n_nodes, n_spheres, n_materials;
+    uint32_t lds_bytes;           // dynamic LDS the extend kernel needs for this scene
+};
+
+struct CameraDev {
+    wfpt_gpu_camera cam;
+    float inv_proj[16];
+    float view[16];
+};
+
+struct Tiling {
+    uint32_t rank, world; // this context owns 8-row bands k with k % world == rank
+};
+
+struct GenerateArgs {
+    RayQueue q;
+    float *image;            // reset to 1 when reset_image != 0
+    Control *ctl;            // frame uniform; fused loop: n_in <- rays generated
+    const CameraDev *camera;
+    uint32_t gx, gy;         // dispatch (gy counts this rank's bands)
+    uint32_t true_size;      // 0: width/height = 8*gx, 8*gy (generate_rays.wgsl:55-56); 1: from the frame uniform
+    uint32_t reset_image;
+    uint32_t set_n_in;       // fused loop: ctl->n_in = gx*gy*64 (pt:313-316)
+    uint32_t capacity;
+    Tiling tile;
+};
+
+struct ExtendArgs {
+    RayQueue q;
+    HitQueue hq;
+    uint32_t *miss_ridx;
+    uint32_t *chunk_hits, *chunk_miss;
+    Control *ctl;
+    const uint32_t *n_in; // rays to trace = min(*n_in, limit)
+    uint32_t limit;
+    uint32_t has_inactive; // ray queue may hold WFPT_INACTIVE_PIXEL padding rays
+    SceneDev scene;
+};
+
+struct ScanArgs {
+    const uint32_t *chunk_hits, *chunk_miss;
+    uint32_t *chunk_hit_base, *chunk_miss_base;
+    Control *ctl;
+    const uint32_t *n_in;
+    uint32_t limit;
+    uint32_t fused;      // 1: drive the device-resident loop; 0: stage API (counters protocol only)
+    uint32_t miss_floor;
+    uint32_t bounce;
+};
+
+struct ShadeArgs {
+    RayQueue q, ext;
+    HitQueue hq;
+    const uint32_t *chunk_hits, *chunk_hit_base;
+    float *image;
+    Control *ctl;
+    const uint32_t *n_hits; // hits to shade = min(*n_hits, limit)
+    uint32_t limit;
+    uint32_t gx;            // stage API: the host's dispatch x extent; 0: use ctl->shade_gx
+    uint32_t rng_mode;
+    uint32_t material;      // 0xffffffff: all; 0/1/2: only that material_type (per-material split)
+    uint32_t count_out;     // stage API: counters[2] += rays emitted (sh:155)
+    uint32_t image_width;   // for the tile mapping
+    SceneDev scene;
+    Tiling tile;
+};
+
+struct MissArgs {
+    RayQueue q;
+    const uint32_t *miss_ridx;
+    const uint32_t *chunk_miss, *chunk_miss_base;
+    float *image;
+    const Control *ctl;
+    const uint32_t *n_miss;
+    uint32_t limit;
+    uint32_t image_width;
+    Tiling tile;
+};
+
+struct AccumulateArgs {
+    const float *image;
+    float *accumulated;
+    Control *ctl;
+    uint32_t n_floats;
+    uint32_t bookkeeping; // fused loop: fold the bounce table into totals, frame += 1
+};
+
+hipError_t launch_generate(const GenerateArgs &a, hipStream_t s);
+hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s);
+hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
+hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s);
+hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
+hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);
+hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s);
+// AoS <-> SoA converters for the read-back / injection paths
+hipError_t launch_rays_to_aos(const RayQueue &q, wfpt_ray *out, uint32_t n, hipStream_t s);
+hipError_t launch_rays_from_aos(const RayQueue &q, const wfpt_ray *in, uint32_t n, hipStream_t s);
+hipError_t launch_selftest_math(int op, const float *a, const float *b, float *out, size_t n, hipStream_t s);
+// Occupancy of the extend kernel for a given dynamic LDS size (workgroups per CU); also raises the
+// kernel's dynamic-LDS limit when the scene needs more than the default 64 KiB.
+hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks);
+uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_spheres);
+
+} // namespace wfpt

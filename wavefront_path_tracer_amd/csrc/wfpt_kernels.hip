@@ -1,0 +1,728 @@
+// wfpt_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the wavefront chain
+//   generate_rays -> extend -> (scan) -> shade -> miss_kernel -> accumulate
+// Hand-written for MI355X: SoA ray queues in HBM with coalesced loads, the whole sphere BVH staged in
+// LDS by persistent extend workgroups, stack-free traversal (pending-level bit trail + parent table, so
+// occupancy is not limited by a per-lane stack), wave64 ballot + mbcnt compaction into queue segments.
+// No MFMA: this is branchy fp32 traversal, not a contraction.
+//
+// Arithmetic follows wfpt_device_math.h exactly (compiled -ffp-contract=off) so results are bit-equal to
+// the oracle's. Citations: gr/ex/sh/mk/ac = gpu_wavefront_pt/shaders/{generate_rays,extend,shade,
+// miss_kernel,accumulate}.wgsl, pt = gpu_wavefront_pt/src/path_tracer.rs.
+#include "wfpt_kernels.h"
+#include "wfpt_device_math.h"
+
+namespace wfpt {
+
+namespace {
+
+constexpr float kPi = 3.1415927f; // gr:2, sh:2
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// pixel index -> slot in this context's image slab (identity unless the image is sharded by bands)
+__device__ __forceinline__ uint32_t local_pixel(uint32_t pixel, uint32_t width, Tiling tile) {
+    if (tile.world <= 1) return pixel;
+    const uint32_t y = pixel / width, x = pixel - y * width;
+    const uint32_t band = y >> 3;
+    return ((band / tile.world) * 8u + (y & 7u)) * width + x;
+}
+
+// WGSL mat4x4f * vec4f, m column-major: ((c0*x + c1*y) + c2*z) + c3*w per component
+struct float4_ { float x, y, z, w; };
+__device__ __forceinline__ float4_ mat_mul(const float *m, float4_ v) {
+    float4_ r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+    r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+    return r;
+}
+
+// gr:107-116
+__device__ __forceinline__ void rng_next_in_unit_disk(uint32_t &state, float &x, float &y) {
+    const float r = sqrt_(rng_next_float(state));
+    const float alpha = 2.0f * kPi * rng_next_float(state);
+    float s, c;
+    sincos_(alpha, s, c);
+    x = r * c;
+    y = r * s;
+}
+
+// sh:203-216
+__device__ __forceinline__ float3_ rng_next_in_unit_sphere(uint32_t &state) {
+    const float r = pow_(rng_next_float(state), 0.33333f);
+    const float cos_theta = 1.0f - 2.0f * rng_next_float(state);
+    const float sin_theta = sqrt_(1.0f - cos_theta * cos_theta);
+    const float phi = 2.0f * kPi * rng_next_float(state);
+    float s, c;
+    sincos_(phi, s, c);
+    return {r * sin_theta * c, r * sin_theta * s, r * cos_theta};
+}
+
+// ================================================================================================
+// generate_rays (gr:42-91): one thread per queue slot, slot = tile*64 + local (8x8-tile order), so a
+// wave is one 8x8 pixel tile and the SoA stores are fully coalesced.
+// ================================================================================================
+__global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_threads = a.gx * a.gy * 64u;
+    if (idx >= n_threads || idx >= a.capacity) return;
+    const uint32_t workgroup_index = idx >> 6, local_index = idx & 63u;
+    const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
+    const uint32_t id_x = wx * 8u + (local_index & 7u);
+    const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
+    const wfpt_frame_buffer fb = a.ctl->frame;
+    if (a.set_n_in && idx == 0) a.ctl->n_in = n_threads; // pt:313-316: counter[2] = rays for the first extend
+    const uint32_t width = a.true_size ? fb.width : a.gx * 8u;   // gr:55-56
+    const uint32_t height = a.true_size ? fb.height : a.gy * 8u;
+
+    if (a.true_size && (id_x >= width || id_y >= height)) { // padding lane of a partial tile
+        a.q.ox[idx] = 0.0f; a.q.oy[idx] = 0.0f; a.q.oz[idx] = 0.0f;
+        a.q.dx[idx] = 0.0f; a.q.dy[idx] = 0.0f; a.q.dz[idx] = 0.0f;
+        a.q.pixel[idx] = WFPT_INACTIVE_PIXEL;
+        return;
+    }
+    const uint32_t pixel_idx = id_x + id_y * width; // gr:57
+    uint32_t rng = init_rng(id_x, id_y, width, fb.frame); // gr:60
+    rng = advance(rng, fb.sample_number * 10u);           // gr:61
+    float off_x, off_y;
+    rng_next_in_unit_disk(rng, off_x, off_y);             // gr:63
+
+    float ndc_x = (static_cast<float>(id_x) + off_x) / static_cast<float>(width); // gr:66
+    float ndc_y = 1.0f - (static_cast<float>(id_y) + off_y) / static_cast<float>(height);
+    ndc_x = 2.0f * ndc_x - 1.0f; // gr:67
+    ndc_y = 2.0f * ndc_y - 1.0f;
+    const CameraDev &cam = *a.camera;
+    float4_ pp = mat_mul(cam.inv_proj, {ndc_x, ndc_y, 1.0f, 1.0f}); // gr:68
+    const float pw = pp.w;
+    pp = {pp.x / pw, pp.y / pw, pp.z / pw, pp.w / pw}; // gr:69
+
+    float4_ origin = {cam.cam.position[0], cam.cam.position[1], cam.cam.position[2], cam.cam.position[3]};
+    if (cam.cam.defocus_radius > 0.0f) { // gr:73-82
+        rng_next_in_unit_disk(rng, off_x, off_y);
+        const float R = cam.cam.defocus_radius;
+        const float4_ p_lens = {R * off_x, R * off_y, R * 0.0f, 1.0f};
+        float4_ lo = mat_mul(cam.view, p_lens);
+        const float lw = lo.w;
+        origin = {lo.x / lw, lo.y / lw, lo.z / lw, lo.w / lw};
+        const float tf = cam.cam.focus_distance / pp.z;
+        pp = {tf * pp.x - p_lens.x, tf * pp.y - p_lens.y, tf * pp.z - p_lens.z, tf * pp.w - p_lens.w};
+    }
+    const float4_ rd = mat_mul(cam.view, {pp.x, pp.y, pp.z, 0.0f}); // gr:84
+    // normalize(vec4) (gr:86): length = sqrt(((x*x + y*y) + z*z) + w*w)
+    const float len = sqrt_(((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z) + rd.w * rd.w);
+
+    a.q.ox[idx] = origin.x; a.q.oy[idx] = origin.y; a.q.oz[idx] = origin.z;
+    a.q.dx[idx] = rd.x / len; a.q.dy[idx] = rd.y / len; a.q.dz[idx] = rd.z / len;
+    a.q.pixel[idx] = pixel_idx;
+    if (a.reset_image) { // pt:305-306 folded in: throughput starts at 1
+        const uint32_t lp = local_pixel(pixel_idx, width, a.tile);
+        a.image[3u * lp + 0u] = 1.0f;
+        a.image[3u * lp + 1u] = 1.0f;
+        a.image[3u * lp + 2u] = 1.0f;
+    }
+}
+
+// ================================================================================================
+// extend (ex:47-210)
+// ================================================================================================
+// ex:164-183 with the node held as two float4 (min.xyz|left_first, max.xyz|prim_count)
+__device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox, float oy, float oz, float ix,
+                                              float iy, float iz, float nearest) {
+    const float t_x_min = (bmin.x - ox) * ix;
+    const float t_x_max = (bmax.x - ox) * ix;
+    float tmin = min_(t_x_min, t_x_max);
+    float tmax = max_(t_x_min, t_x_max);
+    const float t_y_min = (bmin.y - oy) * iy;
+    const float t_y_max = (bmax.y - oy) * iy;
+    tmin = max_(min_(t_y_min, t_y_max), tmin);
+    tmax = min_(max_(t_y_min, t_y_max), tmax);
+    const float t_z_min = (bmin.z - oz) * iz;
+    const float t_z_max = (bmax.z - oz) * iz;
+    tmin = max_(min_(t_z_min, t_z_max), tmin);
+    tmax = min_(max_(t_z_min, t_z_max), tmax);
+    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
+}
+
+// trace_ray (ex:72-162) without a stack. The reference pushes the far child when t_far < nearest and
+// pops LIFO; pushes along one descent have strictly increasing depth, so "the stack" is exactly the set
+// of tree levels with a pending far sibling: one bit per level. Siblings sit at (2k, 2k+1) (bvh.rs:160,
+// 191-206), so the pending node at a level is (path node at that level) ^ 1, and the path node is found
+// by walking `pair_parent` up from the current node. Same visit order, same comparisons, same results as
+// the stack version, but no per-lane stack memory.
+template <typename NodePtr, typename SpherePtr, typename ParentPtr>
+__device__ __forceinline__ bool trace_ray(NodePtr nodes, SpherePtr sphere_geom, ParentPtr pair_parent, float ox,
+                                          float oy, float oz, float dx, float dy, float dz, float &t_out,
+                                          uint32_t &prim_out) {
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
+    const float a = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
+    float nearest = 1e30f;
+    uint32_t best = 0xffffffffu;
+    uint32_t node = 0; // ex:84: the root's box is never tested
+    uint32_t left_first = __float_as_uint(nodes[0].w);
+    uint32_t prim_count = __float_as_uint(nodes[1].w);
+    uint32_t depth = 0;
+    unsigned long long trail = 0;
+    for (;;) {
+        bool pop = true;
+        if (prim_count > 0) { // leaf (ex:86-94)
+            for (uint32_t i = 0; i < prim_count; ++i) {
+                const float4 s = sphere_geom[left_first + i]; // hit(), ex:185-210
+                const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+                const float b = (dx * ocx + dy * ocy) + dz * ocz;
+                const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w * s.w;
+                const float discrim = b * b - a * c;
+                if (discrim >= 0.0f) {
+                    const float sq = sqrt_(discrim);
+                    float t = (-b - sq) / a;
+                    if (t > 0.001f && t < nearest) {
+                        nearest = t;
+                        best = left_first + i;
+                    } else {
+                        t = (-b + sq) / a;
+                        if (t > 0.001f && t < nearest) {
+                            nearest = t;
+                            best = left_first + i;
+                        }
+                    }
+                }
+            }
+        } else { // inner node (ex:105-138)
+            const float4 lmin = nodes[2u * left_first], lmax = nodes[2u * left_first + 1u];
+            const float4 rmin = nodes[2u * left_first + 2u], rmax = nodes[2u * left_first + 3u];
+            const float t_left = hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_right = hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
+            const bool swap = t_left > t_right; // strict: ties keep the left child first
+            const float t_near = swap ? t_right : t_left;
+            const float t_far = swap ? t_left : t_right;
+            if (!(t_near > nearest)) { // ex:124-137: descend into the near child
+                node = left_first + (swap ? 1u : 0u);
+                depth += 1;
+                if (t_far < nearest) trail |= 1ull << depth;
+                left_first = __float_as_uint(swap ? rmin.w : lmin.w);
+                prim_count = __float_as_uint(swap ? rmax.w : lmax.w);
+                pop = false;
+            }
+        }
+        if (pop) {
+            if (trail == 0) break;
+            const uint32_t level = 63u - static_cast<uint32_t>(__clzll(trail));
+            for (uint32_t k = depth; k > level; --k) node = pair_parent[node >> 1];
+            node ^= 1u;
+            trail &= ~(1ull << level);
+            depth = level;
+            left_first = __float_as_uint(nodes[2u * node].w);
+            prim_count = __float_as_uint(nodes[2u * node + 1u].w);
+        }
+    }
+    t_out = nearest;
+    prim_out = best;
+    return nearest < 1e30f; // ex:157
+}
+
+// Persistent workgroups of 512 threads (8 waves): stage the scene in LDS once, then trace queue
+// segments of 512 rays handed out by an atomic ticket. A segment's hits / misses are compacted in
+// thread order into the matching segment of the hit / miss queues with wave64 ballots + mbcnt and one
+// LDS exchange of the eight per-wave counts; no global atomics on queue slots (ex:59,61 use one per ray).
+template <bool HAS_INACTIVE>
+__global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
+    extern __shared__ float4 lds[];
+    const uint32_t n = umin(*a.n_in, a.limit);
+    const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
+    uint32_t chunk = blockIdx.x;
+    if (chunk >= n_chunks) return; // nothing to do: skip the LDS staging too
+
+    float4 *s_nodes = lds;
+    float4 *s_sphere = lds + 2u * a.scene.n_nodes;
+    const uint32_t parent_words = ((a.scene.n_nodes / 2u + 1u) + 7u) / 8u; // uint4 words of 8 u16 entries
+    uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_sphere + a.scene.n_spheres);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_sphere + a.scene.n_spheres + parent_words);
+    // s_misc: [2][2][kExtendWaves] wave counts, then [2] next segment
+    {
+        const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
+        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_nodes[i];
+        for (uint32_t i = threadIdx.x; i < a.scene.n_spheres; i += kExtendThreads) s_sphere[i] = a.scene.sphere_geom[i];
+        const uint4 *g_par = reinterpret_cast<const uint4 *>(a.scene.pair_parent);
+        uint4 *s_par4 = reinterpret_cast<uint4 *>(s_parent);
+        for (uint32_t i = threadIdx.x; i < parent_words; i += kExtendThreads) s_par4[i] = g_par[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t iter = 0;
+    while (chunk < n_chunks) {
+        const uint32_t buf = iter & 1u;
+        if (threadIdx.x == 0) s_misc[4 * kExtendWaves + buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        const uint32_t idx = chunk * kChunk + threadIdx.x; // ex:51
+        bool live = idx < n;                               // ex:53
+        float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+        if (live) {
+            ox = a.q.ox[idx]; oy = a.q.oy[idx]; oz = a.q.oz[idx];
+            dx = a.q.dx[idx]; dy = a.q.dy[idx]; dz = a.q.dz[idx];
+            if (HAS_INACTIVE) live = a.q.pixel[idx] != WFPT_INACTIVE_PIXEL;
+        }
+        float t = 0.0f;
+        uint32_t prim = 0;
+        bool hit = false;
+        if (live) hit = trace_ray(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, t, prim);
+        const bool miss = live && !hit;
+        const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
+        if (lane == 0) {
+            s_misc[(buf * 2 + 0) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(hit_mask));
+            s_misc[(buf * 2 + 1) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(miss_mask));
+        }
+        __syncthreads();
+        uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kExtendWaves; ++w) {
+            const uint32_t h = s_misc[(buf * 2 + 0) * kExtendWaves + w], m = s_misc[(buf * 2 + 1) * kExtendWaves + w];
+            hit_before += (w < wave) ? h : 0u;
+            miss_before += (w < wave) ? m : 0u;
+            hit_total += h;
+            miss_total += m;
+        }
+        const uint32_t seg = chunk * kChunk;
+        if (hit) { // ex:57-59: payload (t, ray_idx, sphere_idx), slot = rank in thread order
+            const uint32_t slot = seg + hit_before + mbcnt(hit_mask);
+            a.hq.t[slot] = t;
+            a.hq.prim[slot] = prim;
+            a.hq.ridx[slot] = idx;
+        }
+        if (miss) a.miss_ridx[seg + miss_before + mbcnt(miss_mask)] = idx; // ex:61
+        if (threadIdx.x == 0) {
+            a.chunk_hits[chunk] = hit_total;
+            a.chunk_miss[chunk] = miss_total;
+        }
+        chunk = s_misc[4 * kExtendWaves + buf];
+        iter += 1;
+    }
+}
+
+// ================================================================================================
+// scan: one workgroup. Exclusive prefix of the per-segment hit / miss counts (=> queue positions in
+// ascending thread order, i.e. the order the oracle resolves ex:59,61's atomicAdd in), the counter
+// protocol of pt:327-353, and for the fused loop the `misses < miss_floor` exit (pt:332) on the device.
+// ================================================================================================
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d, 64);
+        if (static_cast<int>(lane_id()) >= d) v += up;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
+    __shared__ uint32_t s_wave[2][kScanThreads / 64];
+    __shared__ uint32_t s_fac;
+    const uint32_t n = umin(*a.n_in, a.limit);
+    const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t carry_h = 0, carry_m = 0;
+    for (uint32_t base = 0; base < n_chunks; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t vh = i < n_chunks ? a.chunk_hits[i] : 0u;
+        const uint32_t vm = i < n_chunks ? a.chunk_miss[i] : 0u;
+        const uint32_t ih = wave_inclusive_scan(vh), im = wave_inclusive_scan(vm);
+        if (lane == 63) { s_wave[0][wave] = ih; s_wave[1][wave] = im; }
+        __syncthreads();
+        uint32_t before_h = 0, before_m = 0, tile_h = 0, tile_m = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+            const uint32_t h = s_wave[0][w], m = s_wave[1][w];
+            before_h += (w < wave) ? h : 0u;
+            before_m += (w < wave) ? m : 0u;
+            tile_h += h;
+            tile_m += m;
+        }
+        if (i < n_chunks) {
+            a.chunk_hit_base[i] = carry_h + before_h + ih - vh;
+            a.chunk_miss_base[i] = carry_m + before_m + im - vm;
+        }
+        carry_h += tile_h;
+        carry_m += tile_m;
+        __syncthreads();
+    }
+    const uint32_t hits = carry_h, misses = carry_m;
+
+    // x extent of workgroup_size_64(hits) (pt:282-289), the dispatch shape shade.wgsl:72 keys its RNG on
+    const uint32_t q = (hits + 63u) / 64u;
+    uint32_t gx = 1;
+    if (q > 1) {
+        const uint32_t y = static_cast<uint32_t>(__builtin_ceilf(sqrt_(static_cast<float>(q))));
+        if (threadIdx.x == 0) s_fac = 1u;
+        __syncthreads();
+        for (int z = static_cast<int>(y) - 1 - static_cast<int>(threadIdx.x); z >= 1; z -= kScanThreads) {
+            if (q % static_cast<uint32_t>(z) == 0u) {
+                atomicMax(&s_fac, static_cast<uint32_t>(z));
+                break;
+            }
+        }
+        __syncthreads();
+        const uint32_t fac = s_fac;
+        gx = (q / fac >= (1u << 16)) ? y : fac;
+    }
+
+    if (threadIdx.x == 0) {
+        Control *c = a.ctl;
+        c->seg_n = n;
+        c->hits = hits;
+        c->misses = misses;
+        c->shade_gx = gx;
+        c->ticket = 0;
+        if (a.fused) {
+            uint32_t done = (a.bounce == 0) ? 0u : c->done;
+            const uint32_t ran = done ? 0u : 1u;       // this wavefront's extend really ran
+            if (!done && misses < a.miss_floor) done = 1; // pt:332: exit before shading
+            c->done = done;
+            c->shade_n = done ? 0u : hits;
+            c->miss_n = done ? 0u : misses;
+            c->n_in = done ? 0u : hits; // every shaded hit emits exactly one extension ray (sh:155)
+            c->counters[0] = misses;
+            c->counters[1] = hits;
+            c->counters[2] = done ? n : 0u; // pt:335-336
+            if (a.bounce < kMaxRows) {
+                c->rows[a.bounce][0] = ran ? n : 0u;
+                c->rows[a.bounce][1] = hits;
+                c->rows[a.bounce][2] = misses;
+                c->rows[a.bounce][3] = (ran && !done) ? 1u : 0u;
+            }
+            c->bounce = a.bounce + 1;
+        } else {
+            c->counters[1] += hits;   // ex:59
+            c->counters[0] += misses; // ex:61
+        }
+    }
+}
+
+// ================================================================================================
+// shade (sh:56-176)
+// ================================================================================================
+__device__ __forceinline__ float schlick(float cosine, float refraction_index) { // sh:158-162
+    float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow_(1.0f - cosine, 5.0f);
+}
+__device__ __forceinline__ float3_ reflect(float3_ r, float3_ n) { // sh:164-166
+    const float k = 2.0f * dot3(r, n);
+    return {r.x - k * n.x, r.y - k * n.y, r.z - k * n.z};
+}
+
+// Walks the hit-queue segments: segment c holds chunk_hits[c] hits compacted at its front, and
+// chunk_hit_base[c] is the queue position of its first hit, so the logical hit index (the thread index
+// of the reference's shade dispatch) is base + rank. Whole waves beyond a segment's count skip, so lanes
+// stay packed without a global compaction pass. Extension rays go to slot = logical hit index, which is
+// where ascending-order resolution of sh:155's atomicAdd puts them: the next ray queue is compact and
+// keeps the previous order (neighbouring pixels stay neighbours).
+__global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
+    const uint32_t n_hits = umin(*a.n_hits, a.limit); // sh:66
+    const uint32_t n_chunks = (a.ctl->seg_n + kChunk - 1) / kChunk;
+    const wfpt_frame_buffer fb = a.ctl->frame;
+    const uint32_t gx = a.gx ? a.gx : a.ctl->shade_gx;
+    const bool filtered = a.material != 0xffffffffu;
+    if (a.count_out && !filtered && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->counters[2] += n_hits; // sh:155
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t count = a.chunk_hits[chunk];
+        const uint32_t base = a.chunk_hit_base[chunk];
+        if (base >= n_hits) break; // bases ascend with the segment index
+        for (uint32_t r = threadIdx.x; r < count; r += kConsumerThreads) {
+            const uint32_t h = base + r; // the reference's shade thread index
+            if (h >= n_hits) break;
+            const uint32_t slot = chunk * kChunk + r;
+            const float t = a.hq.t[slot];
+            const uint32_t prim = a.hq.prim[slot];
+            const uint32_t ridx = a.hq.ridx[slot];
+            const wfpt_sphere sph = a.scene.spheres[prim];
+            const uint32_t mat_type = sph.material_type; // == payload.mat_type (ex:199)
+            const bool mine = !filtered || a.material == (mat_type > 2u ? 0u : mat_type);
+            if (filtered && a.count_out) { // per-material stage: count only the rays this stage emits
+                const unsigned long long m = __ballot(mine);
+                if (m && lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1))
+                    atomicAdd(&a.ctl->counters[2], static_cast<uint32_t>(__popcll(m)));
+            }
+            if (!mine) continue;
+            const float ox = a.q.ox[ridx], oy = a.q.oy[ridx], oz = a.q.oz[ridx];
+            const float dx = a.q.dx[ridx], dy = a.q.dy[ridx], dz = a.q.dz[ridx];
+            const uint32_t pixel_idx = a.q.pixel[ridx];
+            const wfpt_material mat = a.scene.materials[sph.material_idx];
+
+            // sh:84-87: throughput *= albedo, for every material type
+            const uint32_t lp = local_pixel(pixel_idx, a.image_width, a.tile);
+            float *px = a.image + 3u * static_cast<size_t>(lp);
+            px[0] = px[0] * mat.albedo[0];
+            px[1] = px[1] * mat.albedo[1];
+            px[2] = px[2] * mat.albedo[2];
+
+            // sh:71-73: RNG keyed by the dispatch's global_invocation_id (or by the pixel)
+            uint32_t id_x, id_y;
+            if (a.rng_mode == WFPT_RNG_PIXEL) {
+                id_y = pixel_idx / fb.width;
+                id_x = pixel_idx - id_y * fb.width;
+            } else {
+                const uint32_t wg = h >> 6, li = h & 63u;
+                const uint32_t wgy = wg / gx;
+                id_x = (wg - wgy * gx) * 8u + (li & 7u);
+                id_y = wgy * 8u + (li >> 3);
+            }
+            uint32_t rng = init_rng(id_x, id_y, fb.width, fb.frame);
+            rng = advance(rng, fb.sample_number * 10u);
+
+            // sh:91-93
+            const float p_x = ox + t * dx, p_y = oy + t * dy, p_z = oz + t * dz;
+            const float3_ nrm = normalize3({p_x - sph.center[0], p_y - sph.center[1], p_z - sph.center[2]});
+            const float3_ rdir = {dx, dy, dz};
+            float3_ ext;
+            if (mat_type == 1u) { // sh:110-114 metal
+                const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
+                const float3_ rf = reflect(rdir, nrm);
+                ext = {rf.x + mat.fuzz * rb.x, rf.y + mat.fuzz * rb.y, rf.z + mat.fuzz * rb.z};
+            } else if (mat_type == 2u) { // sh:115-151 dielectric
+                float3_ norm = nrm;
+                const float3_ uv = normalize3(rdir);
+                float cos_theta = min_(dot3(norm, {-uv.x, -uv.y, -uv.z}), 1.0f);
+                float eta;
+                if (cos_theta >= 0.0f) {
+                    eta = 1.0f / mat.refract_index;
+                } else {
+                    eta = mat.refract_index;
+                    norm = {norm.x * -1.0f, norm.y * -1.0f, norm.z * -1.0f};
+                    cos_theta = cos_theta * -1.0f;
+                }
+                const float reflectance = schlick(cos_theta, eta);
+                // refract(), sh:168-176
+                const float ct = dot3(uv, norm);
+                const float k = 1.0f - eta * eta * (1.0f - ct * ct);
+                if (k >= 0.0f) {
+                    if (reflectance > rng_next_float(rng)) {
+                        ext = reflect(uv, norm);
+                    } else {
+                        const float m = eta * ct + sqrt_(k);
+                        ext = {eta * uv.x - m * norm.x, eta * uv.y - m * norm.y, eta * uv.z - m * norm.z};
+                    }
+                } else {
+                    ext = reflect(uv, norm);
+                }
+            } else { // sh:102-109 lambertian (case 0u, default)
+                const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
+                ext = {nrm.x + rb.x, nrm.y + rb.y, nrm.z + rb.z};
+                if (sqrt_(dot3(ext, ext)) < 0.001f) ext = nrm;
+            }
+            // sh:153-155: direction is NOT normalised; invDirection is recomputed by extend
+            a.ext.ox[h] = p_x; a.ext.oy[h] = p_y; a.ext.oz[h] = p_z;
+            a.ext.dx[h] = ext.x; a.ext.dy[h] = ext.y; a.ext.dz[h] = ext.z;
+            a.ext.pixel[h] = pixel_idx;
+        }
+    }
+}
+
+// ================================================================================================
+// miss_kernel (mk:13-38)
+// ================================================================================================
+__global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
+    const uint32_t n_miss = umin(*a.n_miss, a.limit); // mk:24
+    const uint32_t n_chunks = (a.ctl->seg_n + kChunk - 1) / kChunk;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t count = a.chunk_miss[chunk];
+        const uint32_t base = a.chunk_miss_base[chunk];
+        if (base >= n_miss) break;
+        for (uint32_t r = threadIdx.x; r < count; r += kConsumerThreads) {
+            if (base + r >= n_miss) break;
+            const uint32_t ridx = a.miss_ridx[chunk * kChunk + r];
+            const float dy = a.q.dy[ridx];
+            const uint32_t pixel_idx = a.q.pixel[ridx];
+            const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
+            const float om = 1.0f - t;
+            const float cr = om * 1.0f + t * 0.5f; // mk:33
+            const float cg = om * 1.0f + t * 0.7f;
+            const float cb = om * 1.0f + t * 1.0f;
+            float *px = a.image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
+            px[0] *= cr; // mk:35-37
+            px[1] *= cg;
+            px[2] *= cb;
+        }
+    }
+}
+
+// ================================================================================================
+// accumulate (ac:4-17): pure streaming, 16 B per lane
+// ================================================================================================
+__global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
+    const uint32_t n4 = a.n_floats / 4u;
+    const float4 *img4 = reinterpret_cast<const float4 *>(a.image);
+    float4 *acc4 = reinterpret_cast<float4 *>(a.accumulated);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const float4 v = img4[i];
+        float4 s = acc4[i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        acc4[i] = s;
+    }
+    if (blockIdx.x == 0) {
+        const uint32_t tail = 4u * n4 + threadIdx.x;
+        if (tail < a.n_floats) a.accumulated[tail] += a.image[tail];
+        if (a.bookkeeping && threadIdx.x == 0) { // end of a fused sample
+            Control *c = a.ctl;
+            const uint32_t rows = c->bounce < kMaxRows ? c->bounce : kMaxRows;
+            for (uint32_t b = 0; b < rows; ++b) {
+                if (c->rows[b][0] == 0) continue;
+                c->totals[0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
+                c->totals[1] += c->rows[b][1];
+                c->totals[2] += c->rows[b][2];
+            }
+            c->totals[3] += 1;
+            c->samples += 1;
+            c->frame.frame += 1; // RenderProgress::get_next_frame (parameters.rs:78-83) for the next sample
+        }
+    }
+}
+
+// ================================================================================================
+// helpers
+// ================================================================================================
+__global__ void fill_kernel(float *p, float v, size_t n) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        p[i] = v;
+}
+
+__global__ void rays_to_aos_kernel(RayQueue q, wfpt_ray *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    wfpt_ray r;
+    const uint32_t pixel = q.pixel[i];
+    r.origin[0] = q.ox[i]; r.origin[1] = q.oy[i]; r.origin[2] = q.oz[i];
+    r.direction[0] = q.dx[i]; r.direction[1] = q.dy[i]; r.direction[2] = q.dz[i];
+    r.direction[3] = 0.0f;
+    if (pixel == WFPT_INACTIVE_PIXEL) { // padding rays are all-zero in the reference layout
+        r.origin[3] = 0.0f;
+        r.inv_direction[0] = r.inv_direction[1] = r.inv_direction[2] = 0.0f;
+    } else {
+        r.origin[3] = 1.0f;
+        r.inv_direction[0] = 1.0f / r.direction[0]; // gr:87, sh:153
+        r.inv_direction[1] = 1.0f / r.direction[1];
+        r.inv_direction[2] = 1.0f / r.direction[2];
+    }
+    r.pixel_idx = pixel;
+    out[i] = r;
+}
+
+__global__ void rays_from_aos_kernel(RayQueue q, const wfpt_ray *in, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const wfpt_ray r = in[i];
+    q.ox[i] = r.origin[0]; q.oy[i] = r.origin[1]; q.oz[i] = r.origin[2];
+    q.dx[i] = r.direction[0]; q.dy[i] = r.direction[1]; q.dz[i] = r.direction[2];
+    q.pixel[i] = r.pixel_idx;
+}
+
+__global__ void selftest_math_kernel(int op, const float *a, const float *b, float *out, size_t n) {
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b ? b[i] : 0.0f;
+    float r = 0.0f, tmp;
+    switch (op) {
+    case 0: r = sqrt_(x); break;
+    case 1: r = x / y; break;
+    case 2: sincos_(x, r, tmp); break;
+    case 3: sincos_(x, tmp, r); break;
+    case 4: r = pow_(x, y); break;
+    case 5: r = u32_to_unit_float(__float_as_uint(x)); break;
+    case 6: r = min_(x, y); break;
+    case 7: r = max_(x, y); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+} // namespace
+
+// ================================================================================================
+// launchers
+// ================================================================================================
+uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_spheres) {
+    const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
+    return 32u * n_nodes + 16u * n_spheres + 16u * parent_words + 4u * (4u * kExtendWaves + 2u) + 16u;
+}
+
+hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks) {
+    hipError_t e = hipSuccess;
+    if (lds_bytes > 64u * 1024u) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, extend_kernel<false>, kExtendThreads, lds_bytes);
+}
+
+hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
+    const uint32_t n = a.gx * a.gy * 64u;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s) {
+    if (grid == 0) return hipSuccess;
+    if (a.has_inactive)
+        hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(kExtendThreads), a.scene.lds_bytes, s, a);
+    else
+        hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(kExtendThreads), a.scene.lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s) {
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kConsumerThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s) {
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(miss_kernel, dim3(grid), dim3(kConsumerThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid ? grid : 1u), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(fill_kernel, dim3(static_cast<uint32_t>(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_rays_to_aos(const RayQueue &q, wfpt_ray *out, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rays_to_aos_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, q, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_rays_from_aos(const RayQueue &q, const wfpt_ray *in, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rays_from_aos_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, q, in, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_math(int op, const float *a, const float *b, float *out, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(selftest_math_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+} // namespace wfpt

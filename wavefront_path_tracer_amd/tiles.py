@@ -1,0 +1,67 @@
+"""Pixel-tile sharding across GPUs (build-side addition; the reference is single-GPU).
+
+The image is cut into bands of 8 pixel rows (the height of the reference's 8x8 workgroup tile,
+generate_rays.wgsl:42). Band k belongs to rank k % world, so sky, horizon and ground bands are dealt
+round-robin and the ranks stay balanced. Every rank runs the whole kernel chain on its own bands with
+GLOBAL pixel coordinates (so generate_rays is bit-identical to a single-GPU render) and keeps its pixels in
+a compact slab of whole bands. There is no exchange inside the bounce loop; the only collective is one
+gather of the accumulated slabs at the end (RCCL over xGMI when the backend is "nccl").
+"""
+import numpy as np
+
+
+def bands_of(rank, world, height):
+    """Indices of the 8-row bands owned by `rank`."""
+    n_bands = (height + 7) // 8
+    return list(range(rank, n_bands, world))
+
+
+def slab_rows(rank, world, height):
+    """Rows in a rank's slab: whole bands (the last band of the image may be partly outside it)."""
+    return 8 * len(bands_of(rank, world, height))
+
+
+def slab_pixels(rank, world, width, height):
+    return slab_rows(rank, world, height) * width
+
+
+def assemble(slabs, width, height):
+    """Interleave per-rank slabs [(slab_pixels, 3) float32] back into the (width*height, 3) image."""
+    world = len(slabs)
+    out = np.zeros((height, width, 3), np.float32)
+    for rank, slab in enumerate(slabs):
+        rows = np.asarray(slab, np.float32).reshape(-1, width, 3)
+        for local, band in enumerate(bands_of(rank, world, height)):
+            y0 = band * 8
+            n = min(8, height - y0)
+            out[y0:y0 + n] = rows[local * 8:local * 8 + n]
+    return out.reshape(-1, 3)
+
+
+def gather_slabs(local_slab, rank, world, width, height, device=None, group=None):
+    """One gather of every rank's accumulated slab to rank 0 through torch.distributed.
+
+    `local_slab` is either a numpy array (CPU / gloo) or a callable `fill(ptr, n_bytes)` that copies the
+    slab into device memory at `ptr` (GPU / RCCL: wfpt_copy_accumulated_to_device). Returns the assembled
+    (width*height, 3) image on rank 0 and None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    max_floats = 3 * max(slab_pixels(r, world, width, height) for r in range(world))
+    mine = 3 * slab_pixels(rank, world, width, height)
+    dev = torch.device("cpu") if device is None else device
+    send = torch.zeros(max_floats, dtype=torch.float32, device=dev)
+    if callable(local_slab):
+        if mine:
+            local_slab(send.data_ptr(), 4 * mine)
+    else:
+        send[:mine] = torch.from_numpy(np.ascontiguousarray(local_slab, np.float32).reshape(-1)).to(dev)
+    if world == 1:
+        return assemble([send[:mine].cpu().numpy().reshape(-1, 3)], width, height)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, gather_list=recv, dst=0, group=group)
+    if rank != 0:
+        return None
+    slabs = [recv[r][:3 * slab_pixels(r, world, width, height)].cpu().numpy().reshape(-1, 3) for r in range(world)]
+    return assemble(slabs, width, height)
