@@ -916,7 +916,8 @@ uint32_t orc_render_sample(orc_ctx *c) {
         uint32_t rays_in = c->counters[2];
         orc_extend(c, ex, ey);                    /* pt:325 */
         uint32_t num_misses = c->counters[0], num_hits = c->counters[1];
-        c->totals[0] += rays_in; c->totals[1] += num_hits; c->totals[2] += num_misses;
+        /* rays actually traced: true-size padding rays are in rays_in but are neither hits nor misses */
+        c->totals[0] += (uint64_t)num_hits + num_misses; c->totals[1] += num_hits; c->totals[2] += num_misses;
         uint32_t row = c->table_rows < 64 ? c->table_rows++ : 63;
         c->table[row][0] = rays_in; c->table[row][1] = num_hits; c->table[row][2] = num_misses; c->table[row][3] = 0;
         if (num_misses < c->p.miss_floor) break;  /* pt:332 */
