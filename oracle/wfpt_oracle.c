@@ -370,7 +370,7 @@ void orc_gpu_camera_new(const float pos[3], float pitch, float yaw, float defocu
 
 /* pt:282-289. The reference panics (unwrap on None) for x <= 64; the build returns (1,1) there. */
 void orc_workgroup_size_64(uint32_t x, uint32_t *gx, uint32_t *gy) {
-    uint32_t q = (x + 63u) / 64u;
+    uint32_t q = x / 64u + ((x % 64u) ? 1u : 0u); /* u32::div_ceil: no overflow near 2^32 */
     if (q <= 1) { *gx = 1; *gy = 1; return; }
     uint32_t y = (uint32_t)ceilf(sqrtf((float)q));
     uint32_t fac = 1;

@@ -163,3 +163,68 @@ def test_tile_sharding_pixel_mode(gpu, orc):
             pt.close()
         assert_bit_equal(tiles.assemble(slabs, w, h), ref, f"assembled from {world} ranks")
     full.close()
+
+
+# ------------------------------------------------------------------ BASELINE.json's full size, against golden vectors
+@pytest.mark.parametrize("mode", [0, 1])
+def test_full_hd_against_golden(gpu, mode):
+    """1920x1080, 8 bounces (BASELINE config 2's frame) for 2 samples: per-bounce (rays, hits, misses) tables and
+    the SHA-256 of the accumulated image must equal the oracle's committed golden vectors; plus the size-
+    independent properties of the chain."""
+    import hashlib
+    import os
+    W = gpu
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"shirley_1920x1080_mode{mode}.npz"))
+    w, h, spp, bounces = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["bounces"])
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, rng_mode=mode)
+    for s in range(spp):
+        pt.render_sample()
+        t = pt.bounce_table().astype(np.int64)
+        assert np.array_equal(t, g["tables"][s][:len(t)]), f"sample {s}"
+        assert t[0, 0] == w * h and (t[:, 1] + t[:, 2] == t[:, 0]).all() and (t[1:, 0] == t[:-1, 1]).all()
+    acc = pt.accumulated()
+    assert hashlib.sha256(acc.tobytes()).hexdigest() == str(g["acc_sha256"])
+    assert np.array_equal(pt.totals(), g["totals"])
+    assert np.isfinite(acc).all() and acc.min() >= 0.0
+    f = int(g["downsample"])
+    small = acc.reshape(h, w, 3)[:(h // f) * f, :(w // f) * f].reshape(h // f, f, w // f, f, 3).mean(axis=(1, 3))
+    assert np.allclose(small, g["acc_small"], rtol=1e-5, atol=1e-6)
+    pt.close()
+
+
+def test_golden_small_cases_on_gpu(gpu):
+    """The committed stage dumps of the 5-sphere scene (tests/golden/simple_64x64_mode*.npz) straight against the GPU."""
+    import os
+    W = gpu
+    for mode in (0, 1):
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"simple_64x64_mode{mode}.npz"))
+        pt = make_tracer(W, "simple", 64, 64, max_wavefronts=4, rng_mode=mode)
+        pt.render(4)
+        assert_bit_equal(pt.accumulated(), g["acc"], "golden 64x64 image")
+        pt.close()
+
+
+def test_error_paths(gpu):
+    W = gpu
+    pt = make_tracer(W, "simple", 64, 64)
+    with pytest.raises(W.WfptError):
+        pt.generate_ray_kernel.run((4096, 4096))  # dispatch larger than the ray buffer
+    with pytest.raises(W.WfptError):
+        W.Kernel("display", pt)  # not a stage of this path (kernel.rs:36 would panic on the missing shader)
+    with pytest.raises(W.WfptError):
+        pt.hits(10 ** 6)
+    pt.extend_kernel.run((0, 0))  # an empty dispatch is a no-op
+    # update_buffers (path_tracer.rs:240-277): a viewport change zeroes the accumulation and restarts progress
+    pt.render(2)
+    assert pt.accumulated().sum() > 0
+    rp = pt.get_render_parameters()
+    rp.set_viewport((48, 32))
+    pt.update_render_parameters(rp)
+    pt.update_buffers()
+    assert pt.accumulated().sum() == 0 and pt.n_pixels == 48 * 32
+    pt.render(1)
+    assert W.lib().wfpt_frame(pt.handle) == 1
+    with pytest.raises(W.WfptError):
+        rp.set_viewport((640, 480))
+        pt.update_buffers()  # larger than the capacity given at creation
+    pt.close()

@@ -1,0 +1,102 @@
+"""The product's host-side data model (wavefront_path_tracer_amd/csrc/wfpt_host.cpp, through the C ABI) against the
+oracle's independent restatement of wavefront_common: byte-identical scene, BVH, camera and dispatch sizes.
+Runs without a GPU: these entry points touch no device."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+
+def test_scene_new(wf, orc):
+    s = wf.Scene.new()
+    sp, mt = orc.scene_new()
+    assert s.spheres.tobytes() == sp.tobytes() and s.materials.tobytes() == mt.tobytes()
+    # scene.rs:12-46: ground, center, right, left, bubble; materials ground, center, left(glass), right(metal), bubble
+    assert s.spheres["material_idx"].tolist() == [0, 1, 3, 2, 4]
+    assert s.spheres["material_type"].tolist() == [0, 0, 1, 2, 2]
+    assert s.materials["refract_index"][4] == np.float32(1.0) / np.float32(1.5)
+    assert (s.spheres["center"][:, 3] == 1.0).all() and (s.materials["albedo"][:, 3] == 1.0).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 12345])
+def test_book_one_final_and_bvh(wf, orc, seed):
+    s = wf.Scene.book_one_final(seed)
+    sp, mt = orc.scene_book_one_final(seed)
+    assert_bit_equal(s.spheres.view(np.uint8).reshape(-1, 32), sp.view(np.uint8).reshape(-1, 32), "spheres")
+    assert_bit_equal(s.materials.view(np.uint8).reshape(-1, 32), mt.view(np.uint8).reshape(-1, 32), "materials")
+    tree = wf.BVHTree(len(s.spheres))
+    tree.build_bvh_tree(s.spheres)  # reorders in place, bvh.rs:182
+    sp2, nodes = orc.build_bvh(sp)
+    assert_bit_equal(tree.nodes.view(np.uint8).reshape(-1, 32), nodes.view(np.uint8).reshape(-1, 32), "BVH nodes")
+    assert_bit_equal(s.spheres.view(np.uint8).reshape(-1, 32), sp2.view(np.uint8).reshape(-1, 32), "sphere order")
+    # distributions of scene.rs:64-80
+    small = sp[(sp["radius"] == np.float32(0.2))]
+    assert (small["center"][:, 1] == np.float32(0.2)).all()
+    metal = mt[mt["material_type"] == 1]
+    assert (metal["fuzz"] <= 0.5).all() and (metal["albedo"][:-1, :3] >= 0.5).all()
+    assert (mt[mt["material_type"] == 2]["refract_index"] == 1.5).all()
+
+
+def test_bvh_edge_cases(wf):
+    one = np.zeros(1, wf.SPHERE)
+    one["center"][0] = (0, 0, -1, 1)
+    one["radius"] = 0.5
+    t = wf.BVHTree(1)
+    t.build_bvh_tree(one)
+    assert len(t.nodes) == 2 and t.nodes[0]["prim_count"] == 1  # root leaf + the never-used pad (bvh.rs:160-161)
+    with pytest.raises(wf.WfptError):
+        wf.BVHTree(0).build_bvh_tree(np.zeros(0, wf.SPHERE))
+    # coincident centres: no split plane separates them, the node stays a leaf (bvh.rs:186-189)
+    same = np.zeros(4, wf.SPHERE)
+    same["center"][:] = (1, 2, 3, 1)
+    same["radius"] = 0.25
+    t = wf.BVHTree(4)
+    t.build_bvh_tree(same)
+    assert t.nodes[0]["prim_count"] == 4
+
+
+def test_camera_and_projection(wf, orc):
+    cc = wf.CameraController(wf.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
+    for (w, h) in ((1920, 1080), (400, 225), (2880, 1620)):
+        cam, ip, vw = orc.shirley_camera(w, h)
+        assert cc.get_GPU_camera().tobytes() == cam.tobytes()
+        assert cc.get_view_matrix().tobytes() == vw.tobytes()
+        ar = np.float32(w) / np.float32(h)
+        assert wf.ProjectionMatrix(cc.vfov_rad(), ar, 0.1, 100.0).p_inv().tobytes() == ip.tobytes()
+    c2 = wf.Camera((0.0, 0.0, 1.0), (0.0, 0.0, -1.0))  # main.rs:21-22
+    assert abs(c2.pitch - np.pi / 2) < 1e-6 and abs(abs(c2.yaw) - np.pi) < 1e-6
+
+
+def test_workgroup_size_64(wf, orc):
+    for x in list(range(0, 400)) + [4095, 4096, 4097, 90000, 2073600, 4665600, 8294400, 1000003, 1500000, 2 ** 31, 2 ** 32 - 1]:
+        assert wf.workgroup_size_64(x) == orc.workgroup_size_64(x), x
+    gx, gy = wf.workgroup_size_64(2073600)
+    assert (gx, gy) == (162, 200) and gx * gy * 64 >= 2073600
+
+
+def test_render_parameters_and_progress(wf):
+    """wavefront_common/src/parameters.rs:7-101 bookkeeping."""
+    cc = wf.CameraController(wf.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0)
+    rp = wf.RenderParameters(cc, (640, 360))
+    assert not rp.changed()
+    rp.set_viewport((800, 600))
+    assert rp.changed() and rp.viewport_size() == (800, 600)
+    rp.reset()
+    rp.update_camera_controller(cc)
+    assert rp.changed()
+    prog = wf.RenderProgress()
+    f = prog.get_next_frame(rp)
+    assert (f.width, f.height, f.frame, f.sample_number) == (800, 600, 1, 0)  # first frame is 1
+    prog.incr_accumulated_samples(1)
+    assert prog.progress() == pytest.approx(1 / wf.SPP)
+    prog.reset()
+    assert prog.frame == 0 and prog.accumulated_samples() == 0
+    f.set_sample_number(7)
+    assert f.into_array() == [800, 600, 1, 7]
+
+
+def test_tonemap(wf, orc):
+    acc = np.array([[0.0, 4.0, 16.0], [1.0, 100.0, 2.25]], "<f4")
+    got = wf.tonemap_rgb8(acc, 4)  # sqrt(acc / 4) -> 0, 1, 2->clamp, .5, clamp, .75
+    assert got.tolist() == [[0, 255, 255], [128, 255, 191]]
+    assert np.array_equal(got, orc.tonemap_rgb8(acc, 4))
