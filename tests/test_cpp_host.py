@@ -1,0 +1,47 @@
+"""The C++ host mirror (wavefront_path_tracer_amd/host/wfpt.hpp) compiled with g++ against the C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from helpers import inputs_for, make_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(wf, tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "host_mirror"
+    pkg = os.path.join(ROOT, "wavefront_path_tracer_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(pkg, "host"),
+           os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp"), "-o", str(out), "-L", pkg, "-lwfpt", f"-Wl,-rpath,{pkg}",
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    return str(out)
+
+
+def test_cpp_data_model_matches_oracle(exe, orc, tmp_path):
+    out = tmp_path / "model.bin"
+    r = subprocess.run([exe, "model", str(out)], capture_output=True, text=True, check=True)
+    assert r.stdout.split() == ["485", "970", "162", "200"]
+    sp, mt = orc.scene_book_one_final(1)
+    sp, nodes = orc.build_bvh(sp)
+    cam, ip, vw = orc.shirley_camera(1920, 1080)
+    want = sp.tobytes() + mt.tobytes() + nodes.tobytes() + cam.tobytes() + ip.tobytes() + vw.tobytes()
+    assert out.read_bytes() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["run", "render"])
+def test_cpp_path_tracer(gpu, exe, orc, tmp_path, mode):
+    """PathTracer::run() written like path_tracer.rs:279-371, in C++, over libwfpt.so: bit-equal to the oracle."""
+    w, h, spp, bounces = 200, 120, 2, 5
+    out = tmp_path / "acc.bin"
+    r = subprocess.run([exe, mode, str(w), str(h), str(spp), str(bounces), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, "<f4").reshape(-1, 3)
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+    assert_bit_equal(got, o.render(spp), f"C++ PathTracer ({mode})")
+    o.close()
