@@ -40,6 +40,7 @@ def parse():
                     help="auto: dispatch (reference-faithful) on 1 GPU, pixel (shard-invariant) on N > 1")
     ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-stage-times", action="store_true")
@@ -109,7 +110,8 @@ def main():
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
     flags = (W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0)
     pt = W.shirley_path_tracer(args.width, args.height, seed=args.seed, max_wavefronts=args.bounces,
-                               rng_mode=rng_mode, flags=flags, tile_rank=rank, tile_world=world, device=local_rank)
+                               rng_mode=rng_mode, flags=flags, tile_rank=rank, tile_world=world, device=local_rank,
+                               batch=args.batch)
 
     def sync():
         pt.synchronize()
@@ -154,10 +156,9 @@ def main():
         ms = np.zeros(W.STAGE_COUNT, np.float64)
         launches = np.zeros(W.STAGE_COUNT, np.int64)
         r0 = pt.totals().copy()
-        for _ in range(args.steps):
-            m, l = pt.render_sample_timed()
-            ms += m
-            launches += l
+        m, l = pt.render_timed(args.steps)  # same batching as pt.render
+        ms += m
+        launches += l
         rt = pt.totals() - r0
         ext_ms, ext_n = float(ms[W.STAGES["extend"]]), int(launches[W.STAGES["extend"]])
         ext_bytes = 24.0 * float(rt[0]) + 12.0 * float(rt[1]) + 4.0 * float(rt[2])  # 24 B/ray in, 12 B/hit, 4 B/miss
@@ -189,7 +190,7 @@ def main():
                                f"{args.steps} spp, {args.bounces} bounces",
                    "step": "one sample per pixel: generate_rays -> bounces x (extend, scan, shade, miss_kernel) -> accumulate",
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
-                   "launch": "direct" if args.no_graph else "hipGraph",
+                   "launch": "direct" if args.no_graph else "hipGraph", "samples_in_flight": args.batch or 8,
                    "parallelism": "single GPU" if world == 1 else f"pixel bands of 8 rows over {world} GPUs + 1 RCCL gather",
                    "rays_traced": int(rays_total[0])},
     }

@@ -143,6 +143,8 @@ typedef struct wfpt_params {
     uint32_t tile_rank;      /* pixel-tile sharding: this context owns the 8-pixel-high bands k with */
     uint32_t tile_world;     /*   k % tile_world == tile_rank; 0 or 1 = whole image */
     int32_t device;          /* HIP device ordinal */
+    uint32_t batch;          /* samples kept in flight per launch by wfpt_render (1..16; 0 = 8). Results are
+                                bit-identical for every value: samples are independent and accumulate in order. */
 } wfpt_params;
 
 typedef struct wfpt_ctx wfpt_ctx;
@@ -219,7 +221,7 @@ int wfpt_kernel_run(wfpt_ctx *ctx, int stage, uint32_t gx, uint32_t gy);
  * the last <= 10 timed dispatches of that stage; 0 if it never ran. */
 float wfpt_kernel_timing_us(wfpt_ctx *ctx, int stage);
 
-/* PathTracer::run for one sample (path_tracer.rs:291-368) with the whole wavefront loop resident on the
+/* wfpt_render_sample: PathTracer::run for one sample (path_tracer.rs:291-368) with the whole wavefront loop resident on the
  * device: frame += 1, image <- 1, generate, up to max_wavefronts x (extend, shade, miss) with the
  * `misses < miss_floor` exit evaluated on the device, accumulate. No host synchronisation. Sizes that
  * are not multiples of 8 use true-size semantics: out-of-image lanes emit inactive rays. */
@@ -233,6 +235,8 @@ float wfpt_progress(const wfpt_ctx *ctx, uint32_t spp); /* PathTracer::progress 
  * into stage_ms[WFPT_STAGE_COUNT] (+= , caller zeroes) and counts launches in stage_launches (may be
  * NULL). Blocks until the sample is done. */
 int wfpt_render_sample_timed(wfpt_ctx *ctx, float *stage_ms, uint32_t *stage_launches);
+/* n_samples with the same batching as wfpt_render, timed per launch the same way. */
+int wfpt_render_timed(wfpt_ctx *ctx, uint32_t n_samples, float *stage_ms, uint32_t *stage_launches);
 
 /* ------------------------------------------------------------------ read-back (blocking) */
 

@@ -228,3 +228,32 @@ def test_error_paths(gpu):
         rp.set_viewport((640, 480))
         pt.update_buffers()  # larger than the capacity given at creation
     pt.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4, 8, 16])
+def test_batched_samples_equal_sequential(gpu, orc, batch):
+    """wfpt_render keeps `batch` samples in flight per launch; samples are independent and accumulate in frame
+    order, so the image must be bit-equal to one-sample-at-a-time rendering (and to the oracle)."""
+    W = gpu
+    w, h, spp, bounces = 200, 120, 19, 5  # 19 = full batches plus a remainder rendered one by one
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+    want = o.render(spp)
+    for flags in (0, W.FLAG_NO_GRAPH):
+        pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
+        pt.render(spp)
+        assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")
+        assert np.array_equal(pt.totals(), o.totals())
+        assert np.array_equal(pt.bounce_table(), o.bounce_table())  # table of the last sample
+        assert W.lib().wfpt_frame(pt.handle) == spp
+        ms, launches = pt.render_timed(batch)  # one more batch, timed: same results as untimed
+        o2 = o.render(batch)
+        assert_bit_equal(pt.accumulated(), o2, "render_timed")
+        assert launches[W.STAGES["extend"]] == bounces and ms[W.STAGES["extend"]] > 0
+        want = o2
+        spp_done = spp + batch
+        pt.close()
+        # rebuild the oracle state for the second flags pass
+        o.close()
+        o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+        want = o.render(spp)
+    o.close()

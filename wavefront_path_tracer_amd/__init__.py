@@ -61,7 +61,7 @@ class _Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_pixels", C.c_uint32),
                 ("max_wavefronts", C.c_uint32), ("miss_floor", C.c_uint32), ("rng_mode", C.c_uint32),
                 ("flags", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("batch", C.c_uint32)]
 
 
 class GPUFrameBuffer(C.Structure):
@@ -127,6 +127,7 @@ def lib():
         "wfpt_render_sample": (i32, [vp]),
         "wfpt_render": (i32, [vp, u32]),
         "wfpt_render_sample_timed": (i32, [vp, vp, vp]),
+        "wfpt_render_timed": (i32, [vp, u32, vp, vp]),
         "wfpt_synchronize": (i32, [vp]),
         "wfpt_frame": (u32, [vp]),
         "wfpt_accumulated_samples": (u32, [vp]),
@@ -402,7 +403,7 @@ class PathTracer:
     counter read-backs; `render(spp)` is the same loop resident on the device (no host synchronisation)."""
 
     def __init__(self, scene, rp, max_window_size=0, max_wavefronts=50, miss_floor=128, rng_mode=RNG_DISPATCH,
-                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP):
+                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0):
         L = lib()
         self.handle = None
         self.scene = scene
@@ -422,7 +423,7 @@ class PathTracer:
         view = cc.get_view_matrix()
         cam = cc.get_GPU_camera()
         self._params = _Params(w, h, max_window_size, max_wavefronts, miss_floor, rng_mode, flags,
-                               tile_rank, tile_world, device)
+                               tile_rank, tile_world, device, batch)
         self.handle = L.wfpt_create(C.byref(self._params), _p(scene.spheres), len(scene.spheres),
                                     _p(scene.materials), len(scene.materials), _p(bvh.nodes), len(bvh.nodes),
                                     _p(cam), _p(proj), _p(view))
@@ -556,6 +557,13 @@ class PathTracer:
         ms = np.zeros(STAGE_COUNT, "<f4")
         launches = np.zeros(STAGE_COUNT, "<u4")
         self._check(lib().wfpt_render_sample_timed(self.handle, _p(ms), _p(launches)))
+        return ms, launches
+
+    def render_timed(self, n_samples):
+        """Like render(n_samples) (same batching) with hipEvent pairs around every launch: (ms, launches) per stage."""
+        ms = np.zeros(STAGE_COUNT, "<f4")
+        launches = np.zeros(STAGE_COUNT, "<u4")
+        self._check(lib().wfpt_render_timed(self.handle, n_samples, _p(ms), _p(launches)))
         return ms, launches
 
     def synchronize(self):

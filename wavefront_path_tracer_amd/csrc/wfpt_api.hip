@@ -34,6 +34,10 @@ struct wfpt_ctx {
     uint32_t pixel_capacity = 0;
     uint32_t capacity = 0;      // ray-queue slots (multiple of kChunk)
     uint32_t n_chunks_max = 0;
+    uint32_t batch_max = 1;     // samples kept in flight by the device-resident loop
+    size_t image_floats = 0;    // floats per image slice
+    uint32_t cus = 0, blocks_per_cu = 1;
+    uint32_t last_slot = 0;     // batch slice that holds the most recent sample's bounce table
     bool has_inactive = false;
     Tiling tile{0, 1};
 
@@ -54,12 +58,12 @@ struct wfpt_ctx {
     SceneDev scene{};
     std::vector<wfpt_sphere> h_spheres;
 
-    uint32_t extend_grid = 0, consumer_grid = 0, accumulate_grid = 0;
+    uint32_t accumulate_grid = 0;
     uint32_t progress_frame = 0, accumulated_samples = 0;
     bool dev_frame_valid = false;
 
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph[2] = {nullptr, nullptr};       // [0]: one sample, [1]: a full batch
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
 
     StageTimer timers[WFPT_STAGE_COUNT];
     std::vector<hipEvent_t> sample_events; // for wfpt_render_sample_timed
@@ -137,13 +141,34 @@ int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint
 }
 
 void destroy_graph(wfpt_ctx *c) {
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    for (int k = 0; k < 2; ++k) {
+        if (c->graph_exec[k]) { (void)hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; }
+        if (c->graph[k]) { (void)hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; }
+    }
+}
+
+Batch batch_of(const wfpt_ctx *c, uint32_t n) {
+    Batch b{};
+    b.n = n;
+    b.ctl_stride = static_cast<uint32_t>(sizeof(Control) / sizeof(uint32_t));
+    b.ray_stride = 7 * static_cast<size_t>(c->capacity);
+    b.queue_stride = c->capacity;
+    b.chunk_stride = c->n_chunks_max;
+    b.image_stride = c->image_floats;
+    return b;
+}
+uint32_t extend_grid(const wfpt_ctx *c, uint32_t n) {
+    const uint64_t items = static_cast<uint64_t>(c->n_chunks_max) * n;
+    return static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->blocks_per_cu));
+}
+uint32_t consumer_grid(const wfpt_ctx *c, uint32_t n) {
+    return std::min(c->n_chunks_max, std::max(64u, (c->cus * 8u + n - 1) / n));
 }
 
 // ---------------------------------------------------------------- argument builders
-GenerateArgs generate_args(wfpt_ctx *c, uint32_t gx, uint32_t gy, bool fused) {
+GenerateArgs generate_args(wfpt_ctx *c, uint32_t gx, uint32_t gy, bool fused, uint32_t nb = 1) {
     GenerateArgs a{};
+    a.batch = batch_of(c, nb);
     a.q = c->q[c->cur];
     a.image = c->image;
     a.ctl = c->ctl;
@@ -156,8 +181,9 @@ GenerateArgs generate_args(wfpt_ctx *c, uint32_t gx, uint32_t gy, bool fused) {
     a.tile = c->tile;
     return a;
 }
-ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit) {
+ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit, uint32_t nb = 1) {
     ExtendArgs a{};
+    a.batch = batch_of(c, nb);
     a.q = c->q[qi];
     a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
     a.miss_ridx = c->miss_ridx;
@@ -170,8 +196,9 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.scene = c->scene;
     return a;
 }
-ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce) {
+ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce, uint32_t nb = 1) {
     ScanArgs a{};
+    a.batch = batch_of(c, nb);
     a.chunk_hits = c->chunk_hits; a.chunk_miss = c->chunk_miss;
     a.chunk_hit_base = c->chunk_hit_base; a.chunk_miss_base = c->chunk_miss_base;
     a.ctl = c->ctl;
@@ -183,8 +210,9 @@ ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused
     return a;
 }
 ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit, uint32_t gx, uint32_t material,
-                     bool count_out) {
+                     bool count_out, uint32_t nb = 1) {
     ShadeArgs a{};
+    a.batch = batch_of(c, nb);
     a.q = c->q[qi];
     a.ext = c->q[qi ^ 1];
     a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
@@ -202,8 +230,9 @@ ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit
     a.tile = c->tile;
     return a;
 }
-MissArgs miss_args(wfpt_ctx *c, int qi, const uint32_t *n_miss, uint32_t limit) {
+MissArgs miss_args(wfpt_ctx *c, int qi, const uint32_t *n_miss, uint32_t limit, uint32_t nb = 1) {
     MissArgs a{};
+    a.batch = batch_of(c, nb);
     a.q = c->q[qi];
     a.miss_ridx = c->miss_ridx;
     a.chunk_miss = c->chunk_miss; a.chunk_miss_base = c->chunk_miss_base;
@@ -215,8 +244,9 @@ MissArgs miss_args(wfpt_ctx *c, int qi, const uint32_t *n_miss, uint32_t limit) 
     a.tile = c->tile;
     return a;
 }
-AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping) {
+AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping, uint32_t nb = 1) {
     AccumulateArgs a{};
+    a.batch = batch_of(c, nb);
     a.image = c->image;
     a.accumulated = c->accumulated;
     a.ctl = c->ctl;
@@ -227,7 +257,7 @@ AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping)
 
 // One fused sample on the stream (pt:291-368). `ev`: optional (stage, start, stop) event recorder.
 struct EventRec { int stage; hipEvent_t start, stop; };
-int enqueue_sample(wfpt_ctx *c, std::vector<EventRec> *ev) {
+int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     size_t next_event = 0;
     auto timed = [&](int stage, auto &&launch) -> hipError_t {
         if (!ev) return launch();
@@ -252,32 +282,32 @@ int enqueue_sample(wfpt_ctx *c, std::vector<EventRec> *ev) {
     c->cur = 0;
     const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
     WFPT_HIP(c, timed(WFPT_STAGE_GENERATE_RAYS,
-                      [&] { return launch_generate(generate_args(c, c->tiles_x, c->tiles_y_local, true), c->stream); }));
+                      [&] { return launch_generate(generate_args(c, c->tiles_x, c->tiles_y_local, true, nb), c->stream); }));
     for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
         const int qi = static_cast<int>(b & 1u);
         WFPT_HIP(c, timed(WFPT_STAGE_EXTEND, [&] {
-                     return launch_extend(extend_args(c, qi, &c->ctl->n_in, c->capacity), c->extend_grid, c->stream);
+                     return launch_extend(extend_args(c, qi, &c->ctl->n_in, c->capacity, nb), extend_grid(c, nb), c->stream);
                  }));
         WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
-                          [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b), c->stream); }));
+                          [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb), c->stream); }));
         if (split) {
             for (uint32_t m = 0; m < 3; ++m)
                 WFPT_HIP(c, timed(WFPT_STAGE_SHADE_LAMBERTIAN + static_cast<int>(m), [&] {
-                             return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, m, false),
-                                                 c->consumer_grid, c->stream);
+                             return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, m, false, nb),
+                                                 consumer_grid(c, nb), c->stream);
                          }));
         } else {
             WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] {
-                         return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false),
-                                             c->consumer_grid, c->stream);
+                         return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb),
+                                             consumer_grid(c, nb), c->stream);
                      }));
         }
         WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] {
-                     return launch_miss(miss_args(c, qi, &c->ctl->miss_n, c->capacity), c->consumer_grid, c->stream);
+                     return launch_miss(miss_args(c, qi, &c->ctl->miss_n, c->capacity, nb), consumer_grid(c, nb), c->stream);
                  }));
     }
     WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
-                 return launch_accumulate(accumulate_args(c, c->n_pixels, true), c->accumulate_grid, c->stream);
+                 return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
              }));
     return WFPT_OK;
 }
@@ -291,25 +321,38 @@ int ensure_device_frame(wfpt_ctx *c) {
     return WFPT_OK;
 }
 
-int render_one(wfpt_ctx *c) {
+// Renders `nb` samples (frames progress_frame+1 ...) with one pass of the chain; nb is 1 or batch_max.
+int render_batch(wfpt_ctx *c, uint32_t nb) {
     WFPT_HIP(c, hipSetDevice(c->device));
     if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
     if (c->p.flags & WFPT_FLAG_NO_GRAPH) {
-        if (int r = enqueue_sample(c, nullptr); r != WFPT_OK) return r;
+        if (int r = enqueue_batch(c, nullptr, nb); r != WFPT_OK) return r;
     } else {
-        if (!c->graph_exec) {
+        const int slot = nb == 1 ? 0 : 1;
+        if (!c->graph_exec[slot]) {
             WFPT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            const int r = enqueue_sample(c, nullptr);
-            const hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+            const int r = enqueue_batch(c, nullptr, nb);
+            const hipError_t e = hipStreamEndCapture(c->stream, &c->graph[slot]);
             if (r != WFPT_OK) return r;
             if (e != hipSuccess) return hip_fail(c, e, "hipStreamEndCapture");
-            WFPT_HIP(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            WFPT_HIP(c, hipGraphInstantiate(&c->graph_exec[slot], c->graph[slot], nullptr, nullptr, 0));
         }
-        WFPT_HIP(c, hipGraphLaunch(c->graph_exec, c->stream));
+        WFPT_HIP(c, hipGraphLaunch(c->graph_exec[slot], c->stream));
     }
     c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
-    c->progress_frame += 1;      // the device advanced ctl->frame.frame itself
-    c->accumulated_samples += 1; // pt:363
+    c->progress_frame += nb;      // the device advanced ctl->frame.frame itself
+    c->accumulated_samples += nb; // pt:363
+    c->last_slot = nb - 1;
+    return WFPT_OK;
+}
+
+int render_many(wfpt_ctx *c, uint32_t n_samples) {
+    while (n_samples >= c->batch_max && c->batch_max > 1) {
+        if (int r = render_batch(c, c->batch_max); r != WFPT_OK) return r;
+        n_samples -= c->batch_max;
+    }
+    for (; n_samples > 0; --n_samples)
+        if (int r = render_batch(c, 1); r != WFPT_OK) return r;
     return WFPT_OK;
 }
 
@@ -374,7 +417,7 @@ extern "C" {
 
 const char *wfpt_build_info(void) {
     static const std::string info = std::string("arch=gfx950;chunk=") + std::to_string(kChunk) +
-                                    ";extend_threads=" + std::to_string(kExtendThreads) + ";fp=ieee-no-contract";
+                                    ";extend_threads=" + std::to_string(kExtendThreads) + ";max_batch=" + std::to_string(kMaxBatch) + ";fp=ieee-no-contract";
     return info.c_str();
 }
 
@@ -452,31 +495,34 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     if (cap == 0) cap = kChunk;
     c->capacity = static_cast<uint32_t>(cap);
     c->n_chunks_max = c->capacity / kChunk;
+    c->batch_max = params->batch == 0 ? 8u : std::min<uint32_t>(params->batch, kMaxBatch);
+    const size_t nb = c->batch_max;
 
     for (int k = 0; k < 2; ++k) {
-        CREATE_HIP(dmalloc(&c->ray_mem[k], 7 * static_cast<size_t>(c->capacity)));
-        CREATE_HIP(hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * 7 * static_cast<size_t>(c->capacity), c->stream));
+        CREATE_HIP(dmalloc(&c->ray_mem[k], nb * 7 * static_cast<size_t>(c->capacity)));
+        CREATE_HIP(hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * nb * 7 * static_cast<size_t>(c->capacity), c->stream));
         set_queue(c->q[k], c->ray_mem[k], c->capacity);
     }
-    CREATE_HIP(dmalloc(&c->hit_t, c->capacity));
-    CREATE_HIP(dmalloc(&c->hit_prim, c->capacity));
-    CREATE_HIP(dmalloc(&c->hit_ridx, c->capacity));
-    CREATE_HIP(dmalloc(&c->miss_ridx, c->capacity));
-    CREATE_HIP(dmalloc(&c->chunk_hits, c->n_chunks_max));
-    CREATE_HIP(dmalloc(&c->chunk_miss, c->n_chunks_max));
-    CREATE_HIP(dmalloc(&c->chunk_hit_base, c->n_chunks_max));
-    CREATE_HIP(dmalloc(&c->chunk_miss_base, c->n_chunks_max));
-    CREATE_HIP(hipMemsetAsync(c->chunk_hits, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
-    CREATE_HIP(hipMemsetAsync(c->chunk_miss, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
-    CREATE_HIP(hipMemsetAsync(c->chunk_hit_base, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
-    CREATE_HIP(hipMemsetAsync(c->chunk_miss_base, 0, sizeof(uint32_t) * c->n_chunks_max, c->stream));
-    const size_t img_floats = 3 * static_cast<size_t>(c->pixel_capacity) + 4;
-    CREATE_HIP(dmalloc(&c->image, img_floats));
-    CREATE_HIP(dmalloc(&c->accumulated, img_floats));
-    CREATE_HIP(launch_fill(c->image, 1.0f, img_floats, c->stream));                           // pt:53-58
-    CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * img_floats, c->stream));     // pt:60-65
-    CREATE_HIP(dmalloc(&c->ctl, 1));
-    CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control), c->stream));
+    CREATE_HIP(dmalloc(&c->hit_t, nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->hit_prim, nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->hit_ridx, nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->miss_ridx, nb * c->capacity));
+    const size_t n_counts = nb * c->n_chunks_max;
+    CREATE_HIP(dmalloc(&c->chunk_hits, n_counts));
+    CREATE_HIP(dmalloc(&c->chunk_miss, n_counts));
+    CREATE_HIP(dmalloc(&c->chunk_hit_base, n_counts));
+    CREATE_HIP(dmalloc(&c->chunk_miss_base, n_counts));
+    CREATE_HIP(hipMemsetAsync(c->chunk_hits, 0, sizeof(uint32_t) * n_counts, c->stream));
+    CREATE_HIP(hipMemsetAsync(c->chunk_miss, 0, sizeof(uint32_t) * n_counts, c->stream));
+    CREATE_HIP(hipMemsetAsync(c->chunk_hit_base, 0, sizeof(uint32_t) * n_counts, c->stream));
+    CREATE_HIP(hipMemsetAsync(c->chunk_miss_base, 0, sizeof(uint32_t) * n_counts, c->stream));
+    c->image_floats = (3 * static_cast<size_t>(c->pixel_capacity) + 7) / 4 * 4; // slices stay 16-byte aligned
+    CREATE_HIP(dmalloc(&c->image, nb * c->image_floats));
+    CREATE_HIP(dmalloc(&c->accumulated, c->image_floats));
+    CREATE_HIP(launch_fill(c->image, 1.0f, nb * c->image_floats, c->stream));                        // pt:53-58
+    CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->image_floats, c->stream));       // pt:60-65
+    CREATE_HIP(dmalloc(&c->ctl, kMaxBatch));
+    CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control) * kMaxBatch, c->stream));
     CREATE_HIP(dmalloc(&c->camera, 1));
 
     // scene upload (pt:120-128) plus the traversal's LDS-friendly copies
@@ -524,8 +570,8 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     CREATE_HIP(extend_blocks_per_cu(c->scene.lds_bytes, &blocks_per_cu));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     const uint32_t cus = static_cast<uint32_t>(prop.multiProcessorCount);
-    c->extend_grid = std::min(c->n_chunks_max, cus * static_cast<uint32_t>(blocks_per_cu));
-    c->consumer_grid = std::min(c->n_chunks_max, cus * 8u);
+    c->cus = cus;
+    c->blocks_per_cu = static_cast<uint32_t>(blocks_per_cu);
     c->accumulate_grid = std::min<uint32_t>((3u * c->pixel_capacity / 4u + 255u) / 256u, cus * 8u);
     if (c->accumulate_grid == 0) c->accumulate_grid = 1;
     CREATE_HIP(hipStreamSynchronize(c->stream));
@@ -606,7 +652,7 @@ int wfpt_read_counters(wfpt_ctx *c, uint32_t counters[16]) {
 int wfpt_reset_image(wfpt_ctx *c) {
     if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
     WFPT_HIP(c, hipSetDevice(c->device));
-    WFPT_HIP(c, launch_fill(c->image, 1.0f, 3 * static_cast<size_t>(c->pixel_capacity), c->stream));
+    WFPT_HIP(c, launch_fill(c->image, 1.0f, c->image_floats, c->stream));
     return WFPT_OK;
 }
 
@@ -622,7 +668,7 @@ int wfpt_clear_ray_queues(wfpt_ctx *c) {
     WFPT_HIP(c, hipSetDevice(c->device));
     for (int k = 0; k < 2; ++k)
         WFPT_HIP(c, hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * 7 * static_cast<size_t>(c->capacity), c->stream));
-    return WFPT_OK;
+    return WFPT_OK; // slice 0 is the stage API's ray_buffer / extension_ray_buffer
 }
 
 int wfpt_swap_ray_queues(wfpt_ctx *c) {
@@ -648,22 +694,22 @@ int wfpt_kernel_run(wfpt_ctx *c, int stage, uint32_t gx, uint32_t gy) {
         WFPT_HIP(c, launch_generate(generate_args(c, gx, gy, false), c->stream));
         break;
     case WFPT_STAGE_EXTEND:
-        WFPT_HIP(c, launch_extend(extend_args(c, c->cur, &c->ctl->counters[2], threads), c->extend_grid, c->stream));
+        WFPT_HIP(c, launch_extend(extend_args(c, c->cur, &c->ctl->counters[2], threads), extend_grid(c, 1), c->stream));
         WFPT_HIP(c, launch_scan(scan_args(c, &c->ctl->counters[2], threads, false, 0), c->stream));
         break;
     case WFPT_STAGE_SHADE:
         WFPT_HIP(c, launch_shade(shade_args(c, c->cur, &c->ctl->counters[1], threads, gx, 0xffffffffu, true),
-                                 c->consumer_grid, c->stream));
+                                 consumer_grid(c, 1), c->stream));
         break;
     case WFPT_STAGE_SHADE_LAMBERTIAN:
     case WFPT_STAGE_SHADE_METAL:
     case WFPT_STAGE_SHADE_DIELECTRIC:
         WFPT_HIP(c, launch_shade(shade_args(c, c->cur, &c->ctl->counters[1], threads, gx,
                                             static_cast<uint32_t>(stage - WFPT_STAGE_SHADE_LAMBERTIAN), true),
-                                 c->consumer_grid, c->stream));
+                                 consumer_grid(c, 1), c->stream));
         break;
     case WFPT_STAGE_MISS:
-        WFPT_HIP(c, launch_miss(miss_args(c, c->cur, &c->ctl->counters[0], threads), c->consumer_grid, c->stream));
+        WFPT_HIP(c, launch_miss(miss_args(c, c->cur, &c->ctl->counters[0], threads), consumer_grid(c, 1), c->stream));
         break;
     case WFPT_STAGE_ACCUMULATE:
         WFPT_HIP(c, launch_accumulate(accumulate_args(c, threads, false), c->accumulate_grid, c->stream));
@@ -695,33 +741,45 @@ float wfpt_kernel_timing_us(wfpt_ctx *c, int stage) {
 
 int wfpt_render_sample(wfpt_ctx *c) {
     if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
-    return render_one(c);
+    return render_batch(c, 1);
 }
 
 int wfpt_render(wfpt_ctx *c, uint32_t n_samples) {
     if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
-    for (uint32_t s = 0; s < n_samples; ++s)
-        if (int r = render_one(c); r != WFPT_OK) return r;
+    return render_many(c, n_samples);
+}
+
+int wfpt_render_timed(wfpt_ctx *c, uint32_t n_samples, float *stage_ms, uint32_t *stage_launches) {
+    if (!c || !stage_ms) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_timed: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    while (n_samples > 0) {
+        const uint32_t nb = (n_samples >= c->batch_max) ? c->batch_max : 1u; // same batching as wfpt_render
+        if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
+        std::vector<EventRec> ev;
+        if (int r = enqueue_batch(c, &ev, nb); r != WFPT_OK) return r;
+        WFPT_HIP(c, hipStreamSynchronize(c->stream));
+        for (const EventRec &e : ev) {
+            float ms = 0.0f;
+            WFPT_HIP(c, hipEventElapsedTime(&ms, e.start, e.stop));
+            stage_ms[e.stage] += ms;
+            if (stage_launches) stage_launches[e.stage] += 1;
+        }
+        c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
+        c->progress_frame += nb;
+        c->accumulated_samples += nb;
+        c->last_slot = nb - 1;
+        n_samples -= nb;
+    }
     return WFPT_OK;
 }
 
 int wfpt_render_sample_timed(wfpt_ctx *c, float *stage_ms, uint32_t *stage_launches) {
-    if (!c || !stage_ms) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_sample_timed: null argument");
-    WFPT_HIP(c, hipSetDevice(c->device));
-    if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
-    std::vector<EventRec> ev;
-    if (int r = enqueue_sample(c, &ev); r != WFPT_OK) return r;
-    WFPT_HIP(c, hipStreamSynchronize(c->stream));
-    for (const EventRec &e : ev) {
-        float ms = 0.0f;
-        WFPT_HIP(c, hipEventElapsedTime(&ms, e.start, e.stop));
-        stage_ms[e.stage] += ms;
-        if (stage_launches) stage_launches[e.stage] += 1;
-    }
-    c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
-    c->progress_frame += 1;
-    c->accumulated_samples += 1;
-    return WFPT_OK;
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    const uint32_t keep = c->batch_max;
+    c->batch_max = 1;
+    const int r = wfpt_render_timed(c, 1, stage_ms, stage_launches);
+    c->batch_max = keep;
+    return r;
 }
 
 int wfpt_synchronize(wfpt_ctx *c) {
@@ -822,7 +880,7 @@ int wfpt_read_bounce_table(wfpt_ctx *c, uint32_t *rows4, uint32_t max_rows, uint
     WFPT_HIP(c, hipSetDevice(c->device));
     WFPT_HIP(c, hipStreamSynchronize(c->stream));
     Control ctl;
-    WFPT_HIP(c, hipMemcpy(&ctl, c->ctl, sizeof ctl, hipMemcpyDeviceToHost));
+    WFPT_HIP(c, hipMemcpy(&ctl, c->ctl + c->last_slot, sizeof ctl, hipMemcpyDeviceToHost));
     // rows of wavefronts whose extend really ran (the device keeps writing empty rows after the loop exits)
     uint32_t n = 0;
     const uint32_t rows = std::min<uint32_t>(ctl.bounce, kMaxRows);

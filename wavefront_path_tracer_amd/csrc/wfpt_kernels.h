@@ -19,6 +19,7 @@ constexpr int kConsumerThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
 constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64
+constexpr int kMaxBatch = 16;      // samples kept in flight by one launch of the device-resident loop
 
 // SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed.
 struct RayQueue {
@@ -73,7 +74,20 @@ struct Tiling {
     uint32_t rank, world; // this context owns 8-row bands k with k % world == rank
 };
 
+// Sample batching. One launch serves `n` independent samples (frames f0, f0+1, ...): every per-sample
+// buffer is an array of `n` identically laid out slices, `*_stride` elements apart. Sample s keeps its
+// own queues, counts and Control block, so results are exactly those of n sequential samples.
+struct Batch {
+    uint32_t n;            // samples in this launch (1 for the stage API)
+    uint32_t ctl_stride;   // u32 words between Control blocks
+    size_t ray_stride;     // floats between ray-queue slices (7 * capacity)
+    size_t queue_stride;   // elements between hit / miss queue slices (capacity)
+    size_t chunk_stride;   // elements between per-segment count arrays
+    size_t image_stride;   // floats between image slices
+};
+
 struct GenerateArgs {
+    Batch batch;
     RayQueue q;
     float *image;            // reset to 1 when reset_image != 0
     Control *ctl;            // frame uniform; fused loop: n_in <- rays generated
@@ -87,6 +101,7 @@ struct GenerateArgs {
 };
 
 struct ExtendArgs {
+    Batch batch;
     RayQueue q;
     HitQueue hq;
     uint32_t *miss_ridx;
@@ -99,6 +114,7 @@ struct ExtendArgs {
 };
 
 struct ScanArgs {
+    Batch batch;
     const uint32_t *chunk_hits, *chunk_miss;
     uint32_t *chunk_hit_base, *chunk_miss_base;
     Control *ctl;
@@ -110,6 +126,7 @@ struct ScanArgs {
 };
 
 struct ShadeArgs {
+    Batch batch;
     RayQueue q, ext;
     HitQueue hq;
     const uint32_t *chunk_hits, *chunk_hit_base;
@@ -127,6 +144,7 @@ struct ShadeArgs {
 };
 
 struct MissArgs {
+    Batch batch;
     RayQueue q;
     const uint32_t *miss_ridx;
     const uint32_t *chunk_miss, *chunk_miss_base;
@@ -139,6 +157,7 @@ struct MissArgs {
 };
 
 struct AccumulateArgs {
+    Batch batch;
     const float *image;
     float *accumulated;
     Control *ctl;
@@ -148,7 +167,7 @@ struct AccumulateArgs {
 
 hipError_t launch_generate(const GenerateArgs &a, hipStream_t s);
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s);
-hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
+hipError_t launch_scan(const ScanArgs &a, hipStream_t s); // one workgroup per sample
 hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);

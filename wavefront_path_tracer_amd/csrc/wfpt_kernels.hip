@@ -33,6 +33,10 @@ __device__ __forceinline__ uint32_t local_pixel(uint32_t pixel, uint32_t width, 
     return ((band / tile.world) * 8u + (y & 7u)) * width + x;
 }
 
+__device__ __forceinline__ RayQueue slice(RayQueue q, size_t off) {
+    return {q.ox + off, q.oy + off, q.oz + off, q.dx + off, q.dy + off, q.dz + off, q.pixel + off};
+}
+
 // WGSL mat4x4f * vec4f, m column-major: ((c0*x + c1*y) + c2*z) + c3*w per component
 struct float4_ { float x, y, z, w; };
 __device__ __forceinline__ float4_ mat_mul(const float *m, float4_ v) {
@@ -73,12 +77,16 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_threads = a.gx * a.gy * 64u;
     if (idx >= n_threads || idx >= a.capacity) return;
+    const uint32_t sample = blockIdx.y; // batch slice; renders frame (base frame + sample)
+    a.q = slice(a.q, sample * a.batch.ray_stride);
+    a.image += sample * a.batch.image_stride;
     const uint32_t workgroup_index = idx >> 6, local_index = idx & 63u;
     const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
     const uint32_t id_x = wx * 8u + (local_index & 7u);
     const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
-    const wfpt_frame_buffer fb = a.ctl->frame;
-    if (a.set_n_in && idx == 0) a.ctl->n_in = n_threads; // pt:313-316: counter[2] = rays for the first extend
+    wfpt_frame_buffer fb = a.ctl->frame;
+    fb.frame += sample;
+    if (a.set_n_in && idx == 0) a.ctl[sample].n_in = n_threads; // pt:313-316: counter[2] = rays for the first extend
     const uint32_t width = a.true_size ? fb.width : a.gx * 8u;   // gr:55-56
     const uint32_t height = a.true_size ? fb.height : a.gy * 8u;
 
@@ -233,17 +241,32 @@ __device__ __forceinline__ bool trace_ray(NodePtr nodes, SpherePtr sphere_geom, 
 template <bool HAS_INACTIVE>
 __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
     extern __shared__ float4 lds[];
-    const uint32_t n = umin(*a.n_in, a.limit);
-    const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
-    uint32_t chunk = blockIdx.x;
-    if (chunk >= n_chunks) return; // nothing to do: skip the LDS staging too
-
     float4 *s_nodes = lds;
     float4 *s_sphere = lds + 2u * a.scene.n_nodes;
     const uint32_t parent_words = ((a.scene.n_nodes / 2u + 1u) + 7u) / 8u; // uint4 words of 8 u16 entries
     uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_sphere + a.scene.n_spheres);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_sphere + a.scene.n_spheres + parent_words);
-    // s_misc: [2][2][kExtendWaves] wave counts, then [2] next segment
+    // s_misc: [2][2][kExtendWaves] wave counts, [2] next work item, [kMaxBatch] rays per sample,
+    //         [kMaxBatch + 1] first work item of each sample
+    uint32_t *s_next = s_misc + 4 * kExtendWaves;
+    uint32_t *s_rays = s_next + 2;
+    uint32_t *s_first = s_rays + kMaxBatch;
+
+    // Work items are (sample, segment) pairs, numbered sample-major.
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
+            const uint32_t n = umin(a.n_in[static_cast<size_t>(smp) * a.batch.ctl_stride], a.limit);
+            s_rays[smp] = n;
+            s_first[smp] = total;
+            total += (n + kChunk - 1) / kChunk;
+        }
+        s_first[a.batch.n] = total;
+    }
+    __syncthreads();
+    const uint32_t n_items = s_first[a.batch.n];
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return; // nothing to do: skip the LDS staging too
     {
         const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
         for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_nodes[i];
@@ -256,16 +279,23 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t iter = 0;
-    while (chunk < n_chunks) {
+    while (item < n_items) {
         const uint32_t buf = iter & 1u;
-        if (threadIdx.x == 0) s_misc[4 * kExtendWaves + buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        if (threadIdx.x == 0) s_next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        uint32_t smp = 0;
+        while (item >= s_first[smp + 1]) ++smp; // at most batch.n - 1 steps, block-uniform
+        const uint32_t chunk = item - s_first[smp];
+        const uint32_t n = s_rays[smp];
+        const RayQueue q = slice(a.q, smp * a.batch.ray_stride);
+        const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+
         const uint32_t idx = chunk * kChunk + threadIdx.x; // ex:51
         bool live = idx < n;                               // ex:53
         float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
         if (live) {
-            ox = a.q.ox[idx]; oy = a.q.oy[idx]; oz = a.q.oz[idx];
-            dx = a.q.dx[idx]; dy = a.q.dy[idx]; dz = a.q.dz[idx];
-            if (HAS_INACTIVE) live = a.q.pixel[idx] != WFPT_INACTIVE_PIXEL;
+            ox = q.ox[idx]; oy = q.oy[idx]; oz = q.oz[idx];
+            dx = q.dx[idx]; dy = q.dy[idx]; dz = q.dz[idx];
+            if (HAS_INACTIVE) live = q.pixel[idx] != WFPT_INACTIVE_PIXEL;
         }
         float t = 0.0f;
         uint32_t prim = 0;
@@ -287,19 +317,19 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
             hit_total += h;
             miss_total += m;
         }
-        const uint32_t seg = chunk * kChunk;
+        const size_t seg = qo + static_cast<size_t>(chunk) * kChunk;
         if (hit) { // ex:57-59: payload (t, ray_idx, sphere_idx), slot = rank in thread order
-            const uint32_t slot = seg + hit_before + mbcnt(hit_mask);
+            const size_t slot = seg + hit_before + mbcnt(hit_mask);
             a.hq.t[slot] = t;
             a.hq.prim[slot] = prim;
             a.hq.ridx[slot] = idx;
         }
         if (miss) a.miss_ridx[seg + miss_before + mbcnt(miss_mask)] = idx; // ex:61
         if (threadIdx.x == 0) {
-            a.chunk_hits[chunk] = hit_total;
-            a.chunk_miss[chunk] = miss_total;
+            a.chunk_hits[co + chunk] = hit_total;
+            a.chunk_miss[co + chunk] = miss_total;
         }
-        chunk = s_misc[4 * kExtendWaves + buf];
+        item = s_next[buf];
         iter += 1;
     }
 }
@@ -321,7 +351,12 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     __shared__ uint32_t s_wave[2][kScanThreads / 64];
     __shared__ uint32_t s_fac;
-    const uint32_t n = umin(*a.n_in, a.limit);
+    const uint32_t sample = blockIdx.x;
+    a.chunk_hits += sample * a.batch.chunk_stride;
+    a.chunk_miss += sample * a.batch.chunk_stride;
+    a.chunk_hit_base += sample * a.batch.chunk_stride;
+    a.chunk_miss_base += sample * a.batch.chunk_stride;
+    const uint32_t n = umin(a.n_in[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit);
     const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t carry_h = 0, carry_m = 0;
@@ -370,12 +405,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     }
 
     if (threadIdx.x == 0) {
-        Control *c = a.ctl;
+        Control *c = a.ctl + sample;
         c->seg_n = n;
         c->hits = hits;
         c->misses = misses;
         c->shade_gx = gx;
-        c->ticket = 0;
+        if (sample == 0) c->ticket = 0; // extend's work-item ticket lives in the first Control block
         if (a.fused) {
             uint32_t done = (a.bounce == 0) ? 0u : c->done;
             const uint32_t ran = done ? 0u : 1u;       // this wavefront's extend really ran
@@ -421,9 +456,19 @@ __device__ __forceinline__ float3_ reflect(float3_ r, float3_ n) { // sh:164-166
 // where ascending-order resolution of sh:155's atomicAdd puts them: the next ray queue is compact and
 // keeps the previous order (neighbouring pixels stay neighbours).
 __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
-    const uint32_t n_hits = umin(*a.n_hits, a.limit); // sh:66
+    const uint32_t sample = blockIdx.y;
+    wfpt_frame_buffer fb = a.ctl->frame;
+    fb.frame += sample;
+    a.ctl += sample;
+    a.q = slice(a.q, sample * a.batch.ray_stride);
+    a.ext = slice(a.ext, sample * a.batch.ray_stride);
+    a.hq = {a.hq.t + sample * a.batch.queue_stride, a.hq.prim + sample * a.batch.queue_stride,
+            a.hq.ridx + sample * a.batch.queue_stride};
+    a.chunk_hits += sample * a.batch.chunk_stride;
+    a.chunk_hit_base += sample * a.batch.chunk_stride;
+    a.image += sample * a.batch.image_stride;
+    const uint32_t n_hits = umin(a.n_hits[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit); // sh:66
     const uint32_t n_chunks = (a.ctl->seg_n + kChunk - 1) / kChunk;
-    const wfpt_frame_buffer fb = a.ctl->frame;
     const uint32_t gx = a.gx ? a.gx : a.ctl->shade_gx;
     const bool filtered = a.material != 0xffffffffu;
     if (a.count_out && !filtered && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->counters[2] += n_hits; // sh:155
@@ -525,7 +570,14 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
 // miss_kernel (mk:13-38)
 // ================================================================================================
 __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
-    const uint32_t n_miss = umin(*a.n_miss, a.limit); // mk:24
+    const uint32_t sample = blockIdx.y;
+    a.ctl += sample;
+    a.q = slice(a.q, sample * a.batch.ray_stride);
+    a.miss_ridx += sample * a.batch.queue_stride;
+    a.chunk_miss += sample * a.batch.chunk_stride;
+    a.chunk_miss_base += sample * a.batch.chunk_stride;
+    a.image += sample * a.batch.image_stride;
+    const uint32_t n_miss = umin(a.n_miss[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit); // mk:24
     const uint32_t n_chunks = (a.ctl->seg_n + kChunk - 1) / kChunk;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t count = a.chunk_miss[chunk];
@@ -553,30 +605,40 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
 // accumulate (ac:4-17): pure streaming, 16 B per lane
 // ================================================================================================
 __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
+    // accumulated += image_0; += image_1; ... in sample order, so a batch gives exactly the sums that
+    // sequential samples (one accumulate dispatch each, pt:362) would.
     const uint32_t n4 = a.n_floats / 4u;
-    const float4 *img4 = reinterpret_cast<const float4 *>(a.image);
     float4 *acc4 = reinterpret_cast<float4 *>(a.accumulated);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        const float4 v = img4[i];
         float4 s = acc4[i];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
+            const float4 v = reinterpret_cast<const float4 *>(a.image + smp * a.batch.image_stride)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
         acc4[i] = s;
     }
     if (blockIdx.x == 0) {
         const uint32_t tail = 4u * n4 + threadIdx.x;
-        if (tail < a.n_floats) a.accumulated[tail] += a.image[tail];
-        if (a.bookkeeping && threadIdx.x == 0) { // end of a fused sample
-            Control *c = a.ctl;
-            const uint32_t rows = c->bounce < kMaxRows ? c->bounce : kMaxRows;
-            for (uint32_t b = 0; b < rows; ++b) {
-                if (c->rows[b][0] == 0) continue;
-                c->totals[0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
-                c->totals[1] += c->rows[b][1];
-                c->totals[2] += c->rows[b][2];
+        if (tail < a.n_floats) {
+            float s = a.accumulated[tail];
+            for (uint32_t smp = 0; smp < a.batch.n; ++smp) s += a.image[smp * a.batch.image_stride + tail];
+            a.accumulated[tail] = s;
+        }
+        if (a.bookkeeping && threadIdx.x == 0) { // end of a fused batch
+            Control *c0 = a.ctl;
+            for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
+                const Control *c = a.ctl + smp;
+                const uint32_t rows = c->bounce < kMaxRows ? c->bounce : kMaxRows;
+                for (uint32_t b = 0; b < rows; ++b) {
+                    if (c->rows[b][0] == 0) continue;
+                    c0->totals[0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
+                    c0->totals[1] += c->rows[b][1];
+                    c0->totals[2] += c->rows[b][2];
+                }
             }
-            c->totals[3] += 1;
-            c->samples += 1;
-            c->frame.frame += 1; // RenderProgress::get_next_frame (parameters.rs:78-83) for the next sample
+            c0->totals[3] += a.batch.n;
+            c0->samples += a.batch.n;
+            c0->frame.frame += a.batch.n; // RenderProgress::get_next_frame (parameters.rs:78-83) for the next samples
         }
     }
 }
@@ -646,7 +708,7 @@ __global__ void selftest_math_kernel(int op, const float *a, const float *b, flo
 // ================================================================================================
 uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_spheres) {
     const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
-    return 32u * n_nodes + 16u * n_spheres + 16u * parent_words + 4u * (4u * kExtendWaves + 2u) + 16u;
+    return 32u * n_nodes + 16u * n_spheres + 16u * parent_words + 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u) + 16u;
 }
 
 hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks) {
@@ -665,7 +727,7 @@ hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks) {
 hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
     const uint32_t n = a.gx * a.gy * 64u;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(generate_rays_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(generate_rays_kernel, dim3((n + 255u) / 256u, a.batch.n), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -679,19 +741,19 @@ hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s) {
 }
 
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a);
+    hipLaunchKernelGGL(scan_kernel, dim3(a.batch.n), dim3(kScanThreads), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kConsumerThreads), 0, s, a);
+    hipLaunchKernelGGL(shade_kernel, dim3(grid, a.batch.n), dim3(kConsumerThreads), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(miss_kernel, dim3(grid), dim3(kConsumerThreads), 0, s, a);
+    hipLaunchKernelGGL(miss_kernel, dim3(grid, a.batch.n), dim3(kConsumerThreads), 0, s, a);
     return hipGetLastError();
 }
 

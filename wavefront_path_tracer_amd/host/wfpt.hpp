@@ -188,6 +188,7 @@ class PathTracer {
         uint32_t flags = 0, tile_rank = 0, tile_world = 1;
         int32_t device = 0;
         uint32_t spp = SPP;
+        uint32_t batch = 0; // samples in flight per launch of render(); 0 = library default
     };
 
     // PathTracer::new (path_tracer.rs:43-217): builds the BVH (reordering scene.spheres), uploads everything.
@@ -205,7 +206,7 @@ class PathTracer {
         p.width = w; p.height = h; p.max_pixels = opt.max_window_size;
         p.max_wavefronts = opt.max_wavefronts; p.miss_floor = opt.miss_floor;
         p.rng_mode = opt.rng_mode; p.flags = opt.flags;
-        p.tile_rank = opt.tile_rank; p.tile_world = opt.tile_world; p.device = opt.device;
+        p.tile_rank = opt.tile_rank; p.tile_world = opt.tile_world; p.device = opt.device; p.batch = opt.batch;
         ctx_ = wfpt_create(&p, scene.spheres.data(), static_cast<uint32_t>(scene.spheres.size()), scene.materials.data(),
                            static_cast<uint32_t>(scene.materials.size()), bvh_tree_.nodes.data(),
                            static_cast<uint32_t>(bvh_tree_.nodes.size()), &cam, proj.data(), view.data());
