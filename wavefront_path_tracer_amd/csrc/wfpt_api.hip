@@ -466,7 +466,8 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
         return nullptr;
     }
     std::vector<uint16_t> pair_parent;
-    if (validate_bvh(c, nodes, n_nodes, n_spheres, pair_parent) < 0) {
+    const int bvh_depth = validate_bvh(c, nodes, n_nodes, n_spheres, pair_parent);
+    if (bvh_depth < 0) {
         g_last_error = c->err;
         delete c;
         return nullptr;
@@ -549,6 +550,7 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     c->scene.n_spheres = n_spheres;
     c->scene.n_materials = n_materials;
     c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres);
+    c->scene.depth = static_cast<uint32_t>(bvh_depth);
     if (c->scene.lds_bytes > 160u * 1024u) {
         fail(c, WFPT_ERR_UNSUPPORTED, "scene does not fit the 160 KiB LDS of a gfx950 CU");
         g_last_error = c->err;

@@ -62,6 +62,7 @@ struct SceneDev {
     const wfpt_material *materials;
     uint32_t n_nodes, n_spheres, n_materials;
     uint32_t lds_bytes;           // dynamic LDS the extend kernel needs for this scene
+    uint32_t depth;               // levels below the root (validated <= kMaxTrailDepth)
 };
 
 struct CameraDev {

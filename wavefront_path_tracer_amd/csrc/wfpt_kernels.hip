@@ -158,30 +158,85 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
     return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
 }
 
+// Keeps all four components of an LDS float4 live so the load stays one ds_read_b128 (hipcc otherwise
+// narrows it to ds_read_b96 + ds_read_b32, which costs 2.5x the LDS cycles).
+__device__ __forceinline__ float4 lds_load4(const float4 *p) {
+    float4 v = *p;
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+}
+
 // trace_ray (ex:72-162) without a stack. The reference pushes the far child when t_far < nearest and
 // pops LIFO; pushes along one descent have strictly increasing depth, so "the stack" is exactly the set
-// of tree levels with a pending far sibling: one bit per level. Siblings sit at (2k, 2k+1) (bvh.rs:160,
-// 191-206), so the pending node at a level is (path node at that level) ^ 1, and the path node is found
-// by walking `pair_parent` up from the current node. Same visit order, same comparisons, same results as
-// the stack version, but no per-lane stack memory.
-template <typename NodePtr, typename SpherePtr, typename ParentPtr>
-__device__ __forceinline__ bool trace_ray(NodePtr nodes, SpherePtr sphere_geom, ParentPtr pair_parent, float ox,
-                                          float oy, float oz, float dx, float dy, float dz, float &t_out,
+// of tree levels with a pending far sibling: one bit per level (`trail`). Siblings sit at (2k, 2k+1)
+// (bvh.rs:160, 191-206), so the pending node at a level is (path node at that level) ^ 1, and the path
+// node is found by walking `pair_parent` up from the current node. Same visit order, same comparisons,
+// same results as the stack version, but no per-lane stack memory.
+//
+// Scheduling is "while-while": all lanes first run inner-node steps until each sits on a leaf (or is
+// done), then all leaf lanes test their spheres together. Each lane still performs exactly the
+// reference's sequence of operations; only the interleaving across lanes changes, which keeps more lanes
+// active per instruction than alternating leaf/inner work every iteration.
+template <typename Trail>
+struct Traversal {
+    uint32_t node, left_first, prim_count, depth;
+    Trail trail;
+
+    // LIFO pop: deepest pending level. Returns false when nothing is pending (ex:95-97, 125-127: break).
+    __device__ __forceinline__ bool pop(const float4 *nodes, const uint16_t *pair_parent) {
+        if (trail == 0) return false;
+        const uint32_t level = (sizeof(Trail) == 8) ? 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(trail)))
+                                                    : 31u - static_cast<uint32_t>(__clz(static_cast<int>(trail)));
+        for (uint32_t k = depth; k > level; --k) node = pair_parent[node >> 1];
+        node ^= 1u;
+        trail &= ~(static_cast<Trail>(1) << level);
+        depth = level;
+        left_first = __float_as_uint(nodes[2u * node].w);
+        prim_count = __float_as_uint(nodes[2u * node + 1u].w);
+        return true;
+    }
+};
+
+template <typename Trail>
+__device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *sphere_geom, const uint16_t *pair_parent,
+                                          float ox, float oy, float oz, float dx, float dy, float dz, float &t_out,
                                           uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
     const float a = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
-    uint32_t node = 0; // ex:84: the root's box is never tested
-    uint32_t left_first = __float_as_uint(nodes[0].w);
-    uint32_t prim_count = __float_as_uint(nodes[1].w);
-    uint32_t depth = 0;
-    unsigned long long trail = 0;
-    for (;;) {
-        bool pop = true;
-        if (prim_count > 0) { // leaf (ex:86-94)
-            for (uint32_t i = 0; i < prim_count; ++i) {
-                const float4 s = sphere_geom[left_first + i]; // hit(), ex:185-210
+    Traversal<Trail> tr;
+    tr.node = 0; // ex:84: the root's box is never tested
+    tr.left_first = __float_as_uint(nodes[0].w);
+    tr.prim_count = __float_as_uint(nodes[1].w);
+    tr.depth = 0;
+    tr.trail = 0;
+    bool alive = true;
+    while (alive) {
+        // ---- inner nodes (ex:105-138)
+        while (alive && tr.prim_count == 0) {
+            const float4 *pair = nodes + 2u * tr.left_first;
+            const float4 lmin = lds_load4(pair), lmax = lds_load4(pair + 1);
+            const float4 rmin = lds_load4(pair + 2), rmax = lds_load4(pair + 3);
+            const float t_left = hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_right = hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
+            const bool swap = t_left > t_right; // strict: ties keep the left child first
+            const float t_near = swap ? t_right : t_left;
+            const float t_far = swap ? t_left : t_right;
+            if (t_near > nearest) { // ex:124-131
+                alive = tr.pop(nodes, pair_parent);
+            } else { // ex:132-137: descend into the near child, remember the far one
+                tr.node = tr.left_first + (swap ? 1u : 0u);
+                tr.depth += 1;
+                if (t_far < nearest) tr.trail |= static_cast<Trail>(1) << tr.depth;
+                tr.left_first = __float_as_uint(swap ? rmin.w : lmin.w);
+                tr.prim_count = __float_as_uint(swap ? rmax.w : lmax.w);
+            }
+        }
+        // ---- leaf (ex:86-103)
+        if (alive) {
+            for (uint32_t i = 0; i < tr.prim_count; ++i) {
+                const float4 s = sphere_geom[tr.left_first + i]; // hit(), ex:185-210
                 const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
                 const float b = (dx * ocx + dy * ocy) + dz * ocz;
                 const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w * s.w;
@@ -191,42 +246,17 @@ __device__ __forceinline__ bool trace_ray(NodePtr nodes, SpherePtr sphere_geom, 
                     float t = (-b - sq) / a;
                     if (t > 0.001f && t < nearest) {
                         nearest = t;
-                        best = left_first + i;
+                        best = tr.left_first + i;
                     } else {
                         t = (-b + sq) / a;
                         if (t > 0.001f && t < nearest) {
                             nearest = t;
-                            best = left_first + i;
+                            best = tr.left_first + i;
                         }
                     }
                 }
             }
-        } else { // inner node (ex:105-138)
-            const float4 lmin = nodes[2u * left_first], lmax = nodes[2u * left_first + 1u];
-            const float4 rmin = nodes[2u * left_first + 2u], rmax = nodes[2u * left_first + 3u];
-            const float t_left = hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
-            const float t_right = hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
-            const bool swap = t_left > t_right; // strict: ties keep the left child first
-            const float t_near = swap ? t_right : t_left;
-            const float t_far = swap ? t_left : t_right;
-            if (!(t_near > nearest)) { // ex:124-137: descend into the near child
-                node = left_first + (swap ? 1u : 0u);
-                depth += 1;
-                if (t_far < nearest) trail |= 1ull << depth;
-                left_first = __float_as_uint(swap ? rmin.w : lmin.w);
-                prim_count = __float_as_uint(swap ? rmax.w : lmax.w);
-                pop = false;
-            }
-        }
-        if (pop) {
-            if (trail == 0) break;
-            const uint32_t level = 63u - static_cast<uint32_t>(__clzll(trail));
-            for (uint32_t k = depth; k > level; --k) node = pair_parent[node >> 1];
-            node ^= 1u;
-            trail &= ~(1ull << level);
-            depth = level;
-            left_first = __float_as_uint(nodes[2u * node].w);
-            prim_count = __float_as_uint(nodes[2u * node + 1u].w);
+            alive = tr.pop(nodes, pair_parent);
         }
     }
     t_out = nearest;
@@ -238,7 +268,7 @@ __device__ __forceinline__ bool trace_ray(NodePtr nodes, SpherePtr sphere_geom, 
 // segments of 512 rays handed out by an atomic ticket. A segment's hits / misses are compacted in
 // thread order into the matching segment of the hit / miss queues with wave64 ballots + mbcnt and one
 // LDS exchange of the eight per-wave counts; no global atomics on queue slots (ex:59,61 use one per ray).
-template <bool HAS_INACTIVE>
+template <bool HAS_INACTIVE, typename Trail>
 __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
     extern __shared__ float4 lds[];
     float4 *s_nodes = lds;
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
         float t = 0.0f;
         uint32_t prim = 0;
         bool hit = false;
-        if (live) hit = trace_ray(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, t, prim);
+        if (live) hit = trace_ray<Trail>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, t, prim);
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
         if (lane == 0) {
@@ -711,17 +741,25 @@ uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_spheres) {
     return 32u * n_nodes + 16u * n_spheres + 16u * parent_words + 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u) + 16u;
 }
 
+namespace {
+using ExtendFn = void (*)(ExtendArgs);
+ExtendFn extend_variant(bool has_inactive, bool deep) {
+    if (deep) return has_inactive ? extend_kernel<true, unsigned long long> : extend_kernel<false, unsigned long long>;
+    return has_inactive ? extend_kernel<true, uint32_t> : extend_kernel<false, uint32_t>;
+}
+} // namespace
+
 hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks) {
     hipError_t e = hipSuccess;
     if (lds_bytes > 64u * 1024u) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-        if (e != hipSuccess) return e;
+        for (int v = 0; v < 4; ++v) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_variant(v & 1, v & 2)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+            if (e != hipSuccess) return e;
+        }
     }
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, extend_kernel<false>, kExtendThreads, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, extend_kernel<false, unsigned long long>, kExtendThreads,
+                                                        lds_bytes);
 }
 
 hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
@@ -733,10 +771,9 @@ hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
 
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-    if (a.has_inactive)
-        hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(kExtendThreads), a.scene.lds_bytes, s, a);
-    else
-        hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(kExtendThreads), a.scene.lds_bytes, s, a);
+    // a 32-bit trail (one pending bit per tree level) is enough for trees up to 31 levels deep
+    hipLaunchKernelGGL(extend_variant(a.has_inactive != 0, a.scene.depth > 31u), dim3(grid), dim3(kExtendThreads),
+                       a.scene.lds_bytes, s, a);
     return hipGetLastError();
 }
 
