@@ -40,7 +40,7 @@ def parse():
                     help="auto: dispatch (reference-faithful) on 1 GPU, pixel (shard-invariant) on N > 1")
     ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 8)")
+    ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-stage-times", action="store_true")
@@ -190,7 +190,7 @@ def main():
                                f"{args.steps} spp, {args.bounces} bounces",
                    "step": "one sample per pixel: generate_rays -> bounces x (extend, scan, shade, miss_kernel) -> accumulate",
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
-                   "launch": "direct" if args.no_graph else "hipGraph", "samples_in_flight": args.batch or 8,
+                   "launch": "direct" if args.no_graph else "hipGraph", "samples_in_flight": args.batch or 16,
                    "parallelism": "single GPU" if world == 1 else f"pixel bands of 8 rows over {world} GPUs + 1 RCCL gather",
                    "rays_traced": int(rays_total[0])},
     }

@@ -695,6 +695,21 @@ int orc_trace_bvh(orc_ctx *c, const orc_ray *ray, orc_hit_payload *out) {
     return trace_ray_bvh(c, ray, out, &st);
 }
 
+/* Diagnostics for kernel design (not part of the chain): per-ray traversal step counts of the current ray
+ * queue, so lane-utilisation models of the GPU schedule can be evaluated offline. */
+void orc_ray_steps(orc_ctx *c, uint32_t n, uint16_t *inner_steps, uint16_t *leaf_steps) {
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t idx = 0; idx < (int64_t)n; idx++) {
+        trace_stat st = {0, 0, 0};
+        orc_hit_payload payload;
+        if (c->rays[idx].pixel_idx == ORC_INACTIVE_PIXEL) { inner_steps[idx] = 0; leaf_steps[idx] = 0; continue; }
+        trace_ray_bvh(c, &c->rays[idx], &payload, &st);
+        /* every leaf of the seeded scenes holds one sphere, so sphere tests == leaf visits */
+        leaf_steps[idx] = (uint16_t)st.tests;
+        inner_steps[idx] = (uint16_t)(st.nodes - st.tests);
+    }
+}
+
 /* ex:47-70. Phase 1 traces every live thread (parallel, disjoint outputs); phase 2 resolves the two
  * atomicAdd streams in ascending thread index. Rays with pixel_idx == ORC_INACTIVE_PIXEL (true-size
  * padding, never produced with reference-legal sizes) are dropped: neither hit nor miss. */

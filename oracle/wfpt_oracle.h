@@ -126,6 +126,8 @@ void     orc_trace_stats(const orc_ctx *, uint64_t out[4]);
 /* extend.wgsl:141-153 (USE_BVH == false branch): brute-force closest hit, for cross-checks */
 int      orc_trace_brute(const orc_ctx *, const orc_ray *ray, orc_hit_payload *out);
 int      orc_trace_bvh(orc_ctx *, const orc_ray *ray, orc_hit_payload *out);
+/* diagnostics: inner-node and leaf steps of each of the first n rays of the current ray queue */
+void     orc_ray_steps(orc_ctx *, uint32_t n, uint16_t *inner_steps, uint16_t *leaf_steps);
 /* display_shader.wgsl:50-52: sqrt(acc / n) -> 8-bit RGB */
 void     orc_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb);
 int      orc_num_threads(void);

@@ -496,7 +496,7 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     if (cap == 0) cap = kChunk;
     c->capacity = static_cast<uint32_t>(cap);
     c->n_chunks_max = c->capacity / kChunk;
-    c->batch_max = params->batch == 0 ? 8u : std::min<uint32_t>(params->batch, kMaxBatch);
+    c->batch_max = params->batch == 0 ? 16u : std::min<uint32_t>(params->batch, kMaxBatch);
     const size_t nb = c->batch_max;
 
     for (int k = 0; k < 2; ++k) {

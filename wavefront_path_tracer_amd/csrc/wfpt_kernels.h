@@ -19,7 +19,7 @@ constexpr int kConsumerThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
 constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64
-constexpr int kMaxBatch = 16;      // samples kept in flight by one launch of the device-resident loop
+constexpr int kMaxBatch = 64;      // samples kept in flight by one launch of the device-resident loop
 
 // SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed.
 struct RayQueue {
