@@ -55,6 +55,19 @@ typedef struct wfpt_bvh_node {
     uint32_t prim_count;
 } wfpt_bvh_node;
 
+/* BUILD EXTENSION -- the reference intersects spheres only (extend.wgsl:185-210; "other geometric shapes" and
+ * OBJ loading are future items, README.md:22-26). A triangle is a vertex and two edge vectors; the hit test
+ * is Moeller-Trumbore with extend.wgsl's (t_min, t_nearest) window, the shading normal is
+ * normalize(cross(e1, e2)) (never flipped), HitPayload.sphere_idx carries the triangle index. 48 B. */
+typedef struct wfpt_triangle {
+    float v0[3];
+    uint32_t material_idx;
+    float e1[3];
+    uint32_t material_type;
+    float e2[3];
+    uint32_t _pad;
+} wfpt_triangle;
+
 /* wavefront_common/src/camera_controller.rs:161-185 == generate_rays.wgsl:13-19 */
 typedef struct wfpt_gpu_camera {
     float position[4];
@@ -161,6 +174,13 @@ uint32_t wfpt_scene_book_one_final(uint64_t seed, wfpt_sphere *spheres, wfpt_mat
 /* bvh.rs:147-210 (4096-bin SAH): reorders `spheres` in place, writes at most 2*n nodes. */
 int wfpt_build_bvh(wfpt_sphere *spheres, uint32_t n_spheres, wfpt_bvh_node *nodes, uint32_t node_capacity,
                    uint32_t *n_nodes);
+/* Build extension: the same builder over triangles (bin key = centroid v0 + (e1 + e2)/3) with a caller-chosen
+ * number of bins per axis (bvh.rs:4's 4096 is O(10^10) work for a million primitives). Reorders in place. */
+int wfpt_build_bvh_triangles(wfpt_triangle *triangles, uint32_t n_triangles, wfpt_bvh_node *nodes,
+                             uint32_t node_capacity, uint32_t *n_nodes, uint32_t n_bins);
+/* BASELINE config 5: seeded triangle soup -- centres U[-10,10]^3, edges U[-0.05,0.05]^3, material i % 3 over
+ * {Lambertian 0.7, Metal 0.8 fuzz 0.1, Dielectric 1.5}. Writes n triangles and 3 materials; returns 3. */
+uint32_t wfpt_scene_random_mesh(uint64_t seed, uint32_t n_triangles, wfpt_triangle *triangles, wfpt_material *materials);
 /* camera.rs:11-24 */
 void wfpt_camera_new(const float look_from[3], const float look_at[3], float *pitch, float *yaw);
 /* camera.rs:41-69: world-from-camera, 16 floats column-major (columns right, up, dir, position) */
@@ -187,6 +207,13 @@ wfpt_ctx *wfpt_create(const wfpt_params *params,
                       const wfpt_material *materials, uint32_t n_materials,
                       const wfpt_bvh_node *nodes, uint32_t n_nodes,
                       const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]);
+/* Same context over a triangle mesh (build extension). Scenes whose BVH does not fit a CU's LDS are traversed
+ * from HBM / Infinity Cache by a second extend variant. */
+wfpt_ctx *wfpt_create_mesh(const wfpt_params *params,
+                           const wfpt_triangle *triangles, uint32_t n_triangles,
+                           const wfpt_material *materials, uint32_t n_materials,
+                           const wfpt_bvh_node *nodes, uint32_t n_nodes,
+                           const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]);
 void wfpt_destroy(wfpt_ctx *ctx);
 const char *wfpt_last_error(const wfpt_ctx *ctx);
 

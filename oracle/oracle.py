@@ -23,7 +23,9 @@ GPU_CAMERA = np.dtype([("position", "<f4", 4), ("pitch", "<f4"), ("yaw", "<f4"),
 RAY = np.dtype([("origin", "<f4", 4), ("direction", "<f4", 4), ("inv_direction", "<f4", 3),
                 ("pixel_idx", "<u4")])
 HIT = np.dtype([("t", "<f4"), ("ray_idx", "<u4"), ("sphere_idx", "<u4"), ("mat_type", "<u4")])
-assert SPHERE.itemsize == 32 and MATERIAL.itemsize == 32 and BVH_NODE.itemsize == 32
+TRIANGLE = np.dtype([("v0", "<f4", 3), ("material_idx", "<u4"), ("e1", "<f4", 3), ("material_type", "<u4"),
+                     ("e2", "<f4", 3), ("_pad", "<u4")])
+assert SPHERE.itemsize == 32 and MATERIAL.itemsize == 32 and BVH_NODE.itemsize == 32 and TRIANGLE.itemsize == 48
 assert GPU_CAMERA.itemsize == 32 and RAY.itemsize == 48 and HIT.itemsize == 16
 
 RNG_DISPATCH, RNG_PIXEL = 0, 1
@@ -72,6 +74,13 @@ def lib(serial=False):
     L.orc_scene_book_one_final.argtypes = [C.c_uint64, vp, vp]
     L.orc_build_bvh.restype = u32
     L.orc_build_bvh.argtypes = [vp, u32, vp]
+    L.orc_build_bvh_triangles.restype = u32
+    L.orc_build_bvh_triangles.argtypes = [vp, u32, vp, u32]
+    L.orc_scene_random_mesh.restype = u32
+    L.orc_scene_random_mesh.argtypes = [C.c_uint64, u32, vp, vp]
+    L.orc_create_mesh.restype = vp
+    L.orc_create_mesh.argtypes = [C.POINTER(Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]
+    L.orc_ray_steps.argtypes = [vp, u32, vp, vp]
     L.orc_camera_new.argtypes = [vp, vp, C.POINTER(f32), C.POINTER(f32)]
     L.orc_view_transform.argtypes = [vp, f32, f32, vp]
     L.orc_p_inv.argtypes = [f32, f32, f32, f32, vp]
@@ -146,6 +155,26 @@ def build_bvh(spheres, serial=False):
     return sp, nodes[:n].copy()
 
 
+def scene_random_mesh(n, seed=1):
+    """BASELINE config 5's triangle soup: (triangles, materials)."""
+    tris, mt = np.zeros(n, TRIANGLE), np.zeros(3, MATERIAL)
+    lib().orc_scene_random_mesh(seed, n, _p(tris), _p(mt))
+    return tris, mt
+
+
+def build_bvh_triangles(triangles, n_bins=32):
+    """Returns (reordered triangles, nodes)."""
+    tr = np.ascontiguousarray(triangles).copy()
+    nodes = np.zeros(2 * max(len(tr), 1) + 2, BVH_NODE)
+    n = lib().orc_build_bvh_triangles(_p(tr), len(tr), _p(nodes), n_bins)
+    return tr, nodes[:n].copy()
+
+
+def mesh_camera(width, height):
+    """camera at (0,0,30) looking at the origin, vfov 40, no defocus."""
+    return camera((0.0, 0.0, 30.0), (0.0, 0.0, 0.0), 40.0, 0.0, 10.0, 0.1, 100.0, width, height)
+
+
 def camera(look_from, look_at, vfov_deg, defocus_deg, focus_dist, z_near, z_far, width, height):
     """main.rs:23-32 + path_tracer.rs:132-156: returns (gpu_camera, inv_proj[16], view[16])."""
     L = lib()
@@ -178,14 +207,19 @@ def workgroup_size_64(x):
 class Oracle:
     def __init__(self, width, height, spheres, materials, nodes, cam, inv_proj, view,
                  max_wavefronts=50, miss_floor=128, rng_mode=RNG_DISPATCH, tile_rank=0, tile_world=1,
-                 serial=False):
+                 serial=False, triangles=None):
         self.L = lib(serial)
         self.width, self.height = width, height
         self.params = Params(width, height, max_wavefronts, miss_floor, rng_mode, tile_rank, tile_world)
         self._keep = [np.ascontiguousarray(a) for a in (spheres, materials, nodes, cam, inv_proj, view)]
         sp, mt, nd, cm, ip, vw = self._keep
-        self.h = self.L.orc_create(C.byref(self.params), _p(sp), len(sp), _p(mt), len(mt), _p(nd), len(nd),
-                                   _p(cm), _p(ip), _p(vw))
+        if triangles is not None:
+            tr = np.ascontiguousarray(triangles, TRIANGLE)
+            self.h = self.L.orc_create_mesh(C.byref(self.params), _p(tr), len(tr), _p(mt), len(mt), _p(nd), len(nd),
+                                            _p(cm), _p(ip), _p(vw))
+        else:
+            self.h = self.L.orc_create(C.byref(self.params), _p(sp), len(sp), _p(mt), len(mt), _p(nd), len(nd),
+                                       _p(cm), _p(ip), _p(vw))
         self.n_pixels = self.L.orc_n_pixels(self.h)
         self.n_slots = max(self.n_pixels, ((width + 7) // 8) * 64 *
                            (((height + 7) // 8 - tile_rank + tile_world - 1) // tile_world))
@@ -299,6 +333,14 @@ def tonemap_rgb8(acc, n_samples):
     out = np.zeros(a.size, np.uint8)
     lib().orc_tonemap_rgb8(_p(a), a.size // 3, n_samples, _p(out))
     return out.reshape(-1, 3)
+
+
+def mesh_oracle(width, height, n_triangles, seed=1, n_bins=32, **kw):
+    """Config helper: seeded triangle soup + BVH + the C5 camera."""
+    tris, mt = scene_random_mesh(n_triangles, seed)
+    tris, nodes = build_bvh_triangles(tris, n_bins)
+    cam, ip, vw = mesh_camera(width, height)
+    return Oracle(width, height, np.zeros(1, SPHERE), mt, nodes, cam, ip, vw, triangles=tris, **kw)
 
 
 def shirley_oracle(width, height, seed=1, **kw):

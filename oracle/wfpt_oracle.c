@@ -25,7 +25,7 @@
 #endif
 
 #define ORC_PI 3.1415927f /* gr:2, sh:2 */
-#define ORC_MAX_STACK 64  /* ex:38 has STACKSIZE = 10 and no overflow check; see orc_trace_bvh */
+#define ORC_MAX_STACK 128  /* ex:38 has STACKSIZE = 10 and no overflow check; see orc_trace_bvh */
 
 /* ------------------------------------------------------------------------------------------------
  * small vector helpers: fixed association order, no fused operations (build with -ffp-contract=off)
@@ -190,11 +190,36 @@ static void sphere_aabb(const orc_sphere *s, v3 *mn, v3 *mx) { /* sphere.rs:22-2
     *mn = v3_make(s->center[0] - s->radius, s->center[1] - s->radius, s->center[2] - s->radius);
     *mx = v3_make(s->center[0] + s->radius, s->center[1] + s->radius, s->center[2] + s->radius);
 }
-static void node_update_bounds(orc_bvh_node *nd, const orc_sphere *sp) { /* bvh.rs:58-70 */
+/* The builder of bvh.rs only needs a box, a binning key (the sphere's centre) and a swap per primitive.
+ * Triangles (build extension, no reference code) plug in here: box of the three vertices, key = centroid
+ * v0 + (e1 + e2) * (1/3). */
+typedef struct { void *base; int kind; } prim_view; /* kind 0: orc_sphere, 1: orc_triangle */
+static void prim_aabb(const prim_view *pv, uint32_t i, v3 *mn, v3 *mx) {
+    if (pv->kind == 0) { sphere_aabb(&((const orc_sphere *)pv->base)[i], mn, mx); return; }
+    const orc_triangle *t = &((const orc_triangle *)pv->base)[i];
+    v3 p0 = v3_make(t->v0[0], t->v0[1], t->v0[2]);
+    v3 p1 = v3_make(t->v0[0] + t->e1[0], t->v0[1] + t->e1[1], t->v0[2] + t->e1[2]);
+    v3 p2 = v3_make(t->v0[0] + t->e2[0], t->v0[1] + t->e2[1], t->v0[2] + t->e2[2]);
+    *mn = v3_make(fmin_(fmin_(p0.x, p1.x), p2.x), fmin_(fmin_(p0.y, p1.y), p2.y), fmin_(fmin_(p0.z, p1.z), p2.z));
+    *mx = v3_make(fmax_(fmax_(p0.x, p1.x), p2.x), fmax_(fmax_(p0.y, p1.y), p2.y), fmax_(fmax_(p0.z, p1.z), p2.z));
+}
+static float prim_key(const prim_view *pv, uint32_t i, int axis) {
+    if (pv->kind == 0) return ((const orc_sphere *)pv->base)[i].center[axis];
+    const orc_triangle *t = &((const orc_triangle *)pv->base)[i];
+    return t->v0[axis] + (t->e1[axis] + t->e2[axis]) * 0.33333334f;
+}
+static void prim_swap(const prim_view *pv, int64_t i, int64_t j) {
+    if (pv->kind == 0) {
+        orc_sphere *a = (orc_sphere *)pv->base, t = a[i]; a[i] = a[j]; a[j] = t;
+    } else {
+        orc_triangle *a = (orc_triangle *)pv->base, t = a[i]; a[i] = a[j]; a[j] = t;
+    }
+}
+static void node_update_bounds(orc_bvh_node *nd, const prim_view *sp) { /* bvh.rs:58-70 */
     v3 mn = v3_make(INFINITY, INFINITY, INFINITY), mx = v3_make(-INFINITY, -INFINITY, -INFINITY);
     for (uint32_t i = 0; i < nd->prim_count; i++) {
         v3 a, b;
-        sphere_aabb(&sp[nd->left_first + i], &a, &b);
+        prim_aabb(sp, nd->left_first + i, &a, &b);
         mn = v3_make(fmin_(mn.x, a.x), fmin_(mn.y, a.y), fmin_(mn.z, a.z));
         mx = v3_make(fmax_(mx.x, b.x), fmax_(mx.y, b.y), fmax_(mx.z, b.z));
     }
@@ -209,51 +234,53 @@ static float node_cost(const orc_bvh_node *nd) { /* bvh.rs:51-56 */
 }
 
 typedef struct {
-    orc_bin bins[ORC_BINS];
-    uint32_t left_count[ORC_BINS - 1], right_count[ORC_BINS - 1];
-    float left_area[ORC_BINS - 1], right_area[ORC_BINS - 1];
+    int n_bins; /* bvh.rs:4 fixes 4096; the mesh builder may use fewer */
+    orc_bin *bins;
+    uint32_t *left_count, *right_count;
+    float *left_area, *right_area;
 } split_scratch;
 
 /* bvh.rs:73-139 */
-static void find_best_split_plane(const orc_bvh_node *nd, const orc_sphere *sp, split_scratch *w,
+static void find_best_split_plane(const orc_bvh_node *nd, const prim_view *sp, split_scratch *w,
                                   float *out_cost, int *out_axis, float *out_plane) {
     float extent[3] = {nd->aabb_max[0] - nd->aabb_min[0], nd->aabb_max[1] - nd->aabb_min[1],
                        nd->aabb_max[2] - nd->aabb_min[2]};
     uint32_t start = nd->left_first;
+    const int nb = w->n_bins;
     float low_cost = INFINITY;
     int best_axis = 0;
     float best_plane = 0.0f;
     for (int axis = 0; axis < 3; axis++) {
         if (extent[axis] < 0.00001f) continue;
-        for (int i = 0; i < ORC_BINS; i++) bin_default(&w->bins[i]);
-        float scale = (float)ORC_BINS / extent[axis];
+        for (int i = 0; i < nb; i++) bin_default(&w->bins[i]);
+        float scale = (float)nb / extent[axis];
         float min_bound = nd->aabb_min[axis];
         for (uint32_t i = 0; i < nd->prim_count; i++) {
-            float f = (sp[i + start].center[axis] - min_bound) * scale;
+            float f = (prim_key(sp, i + start, axis) - min_bound) * scale;
             /* Rust `as usize` saturates: NaN/negative -> 0 */
             size_t bi = (f > 0.0f) ? ((f >= 4294967040.0f) ? (size_t)0xffffffffu : (size_t)f) : 0;
-            if (bi > ORC_BINS - 1) bi = ORC_BINS - 1;
+            if (bi > (size_t)(nb - 1)) bi = (size_t)(nb - 1);
             v3 a, b;
-            sphere_aabb(&sp[i + start], &a, &b);
+            prim_aabb(sp, i + start, &a, &b);
             bin_expand(&w->bins[bi], a, b);
         }
         orc_bin left_sum, right_sum;
         bin_default(&left_sum);
         bin_default(&right_sum);
-        for (int idx = 0; idx < ORC_BINS - 1; idx++) {
+        for (int idx = 0; idx < nb - 1; idx++) {
             left_sum.prim_count += w->bins[idx].prim_count;
             w->left_count[idx] = left_sum.prim_count;
-            right_sum.prim_count += w->bins[ORC_BINS - 1 - idx].prim_count;
-            w->right_count[ORC_BINS - 2 - idx] = right_sum.prim_count;
+            right_sum.prim_count += w->bins[nb - 1 - idx].prim_count;
+            w->right_count[nb - 2 - idx] = right_sum.prim_count;
             bin_expand(&left_sum, w->bins[idx].mn, w->bins[idx].mx);
             left_sum.prim_count -= 1;
             w->left_area[idx] = bin_area(&left_sum);
-            bin_expand(&right_sum, w->bins[ORC_BINS - 1 - idx].mn, w->bins[ORC_BINS - 1 - idx].mx);
+            bin_expand(&right_sum, w->bins[nb - 1 - idx].mn, w->bins[nb - 1 - idx].mx);
             right_sum.prim_count -= 1;
-            w->right_area[ORC_BINS - 2 - idx] = bin_area(&right_sum);
+            w->right_area[nb - 2 - idx] = bin_area(&right_sum);
         }
-        float inv_bins = 1.0f / (float)ORC_BINS;
-        for (int idx = 0; idx < ORC_BINS - 1; idx++) {
+        float inv_bins = 1.0f / (float)nb;
+        for (int idx = 0; idx < nb - 1; idx++) {
             float cost = (float)w->left_count[idx] * w->left_area[idx] +
                          (float)w->right_count[idx] * w->right_area[idx];
             if (cost < low_cost) {
@@ -271,7 +298,7 @@ static void find_best_split_plane(const orc_bvh_node *nd, const orc_sphere *sp, 
 typedef struct { orc_bvh_node *nodes; uint32_t n_nodes; split_scratch *scratch; } bvh_builder;
 
 /* bvh.rs:166-210 (signed indices: the reference's `j -= 1` on usize can underflow) */
-static void subdivide(bvh_builder *bb, uint32_t index, orc_sphere *sp) {
+static void subdivide(bvh_builder *bb, uint32_t index, const prim_view *sp) {
     float split_cost, plane;
     int axis;
     find_best_split_plane(&bb->nodes[index], sp, bb->scratch, &split_cost, &axis, &plane);
@@ -280,12 +307,10 @@ static void subdivide(bvh_builder *bb, uint32_t index, orc_sphere *sp) {
     int64_t i = bb->nodes[index].left_first;
     int64_t j = i + (int64_t)bb->nodes[index].prim_count - 1;
     while (i <= j) {
-        if (sp[i].center[axis] < plane) {
+        if (prim_key(sp, (uint32_t)i, axis) < plane) {
             i += 1;
         } else {
-            orc_sphere t = sp[i];
-            sp[i] = sp[j];
-            sp[j] = t;
+            prim_swap(sp, i, j);
             j -= 1;
         }
     }
@@ -305,19 +330,64 @@ static void subdivide(bvh_builder *bb, uint32_t index, orc_sphere *sp) {
 }
 
 /* bvh.rs:152-164 */
-uint32_t orc_build_bvh(orc_sphere *sp, uint32_t n, orc_bvh_node *nodes) {
+static uint32_t build_bvh_generic(const prim_view *pv, uint32_t n, orc_bvh_node *nodes, int n_bins) {
     bvh_builder bb;
+    split_scratch sc;
+    sc.n_bins = n_bins;
+    sc.bins = (orc_bin *)malloc(sizeof(orc_bin) * n_bins);
+    sc.left_count = (uint32_t *)malloc(sizeof(uint32_t) * n_bins);
+    sc.right_count = (uint32_t *)malloc(sizeof(uint32_t) * n_bins);
+    sc.left_area = (float *)malloc(sizeof(float) * n_bins);
+    sc.right_area = (float *)malloc(sizeof(float) * n_bins);
     bb.nodes = nodes;
     bb.n_nodes = 0;
-    bb.scratch = (split_scratch *)malloc(sizeof(split_scratch));
+    bb.scratch = &sc;
     orc_bvh_node root = {{0, 0, 0}, 0, {0, 0, 0}, n};
-    node_update_bounds(&root, sp);
+    node_update_bounds(&root, pv);
     nodes[bb.n_nodes++] = root;
     orc_bvh_node pad = {{0, 0, 0}, 0, {0, 0, 0}, 0}; /* bvh.rs:160-161: index 1 is never used */
     nodes[bb.n_nodes++] = pad;
-    subdivide(&bb, 0, sp);
-    free(bb.scratch);
+    subdivide(&bb, 0, pv);
+    free(sc.bins); free(sc.left_count); free(sc.right_count); free(sc.left_area); free(sc.right_area);
     return bb.n_nodes;
+}
+uint32_t orc_build_bvh(orc_sphere *sp, uint32_t n, orc_bvh_node *nodes) {
+    prim_view pv = {sp, 0};
+    return build_bvh_generic(&pv, n, nodes, ORC_BINS);
+}
+/* Build extension: the same builder over triangles, with a caller-chosen bin count (4096 bins per axis per
+ * node, bvh.rs:4, is O(10^10) work for a million primitives). */
+uint32_t orc_build_bvh_triangles(orc_triangle *tris, uint32_t n, orc_bvh_node *nodes, uint32_t n_bins) {
+    prim_view pv = {tris, 1};
+    return build_bvh_generic(&pv, n, nodes, (int)(n_bins < 2 ? 2 : n_bins));
+}
+
+/* BASELINE config 5: n triangles, centres U[-10,10]^3, edge vectors U[-0.05,0.05]^3, material
+ * type i % 3 over three shared materials: Lambertian 0.7 grey, Metal (0.8,0.8,0.8) fuzz 0.1, Dielectric 1.5.
+ * Draw order per triangle: centre x,y,z, e1 x,y,z, e2 x,y,z; v0 = centre - (e1 + e2) * (1/3). */
+uint32_t orc_scene_random_mesh(uint64_t seed, uint32_t n, orc_triangle *tris, orc_material *mt) {
+    uint64_t rng[2];
+    orc_scene_rng_seed(rng, seed);
+    mt[0] = mat_lambertian(0.7f, 0.7f, 0.7f);
+    mt[1] = mat_metal(0.8f, 0.8f, 0.8f, 0.1f);
+    mt[2] = mat_dielectric(1.5f);
+    for (uint32_t i = 0; i < n; i++) {
+        float c[3], e1[3], e2[3];
+        for (int k = 0; k < 3; k++) c[k] = scene_range(rng, -10.0f, 10.0f);
+        for (int k = 0; k < 3; k++) e1[k] = scene_range(rng, -0.05f, 0.05f);
+        for (int k = 0; k < 3; k++) e2[k] = scene_range(rng, -0.05f, 0.05f);
+        orc_triangle t;
+        for (int k = 0; k < 3; k++) {
+            t.v0[k] = c[k] - (e1[k] + e2[k]) * 0.33333334f;
+            t.e1[k] = e1[k];
+            t.e2[k] = e2[k];
+        }
+        t.material_idx = i % 3u;
+        t.material_type = i % 3u;
+        t._pad = 0;
+        tris[i] = t;
+    }
+    return 3;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -404,6 +474,7 @@ struct orc_ctx {
     uint32_t n_slots;    /* ray-queue capacity */
     uint32_t tiles_x, tiles_y_local;
     orc_sphere *spheres; uint32_t n_spheres;
+    orc_triangle *triangles; uint32_t n_triangles; /* build extension: when set, the primitives are triangles */
     orc_material *materials; uint32_t n_materials;
     orc_bvh_node *nodes; uint32_t n_nodes;
     orc_gpu_camera camera;
@@ -473,9 +544,20 @@ orc_ctx *orc_create(const orc_params *p, const orc_sphere *sp, uint32_t ns, cons
     return c;
 }
 
+orc_ctx *orc_create_mesh(const orc_params *p, const orc_triangle *tris, uint32_t nt, const orc_material *mt, uint32_t nm,
+                         const orc_bvh_node *nd, uint32_t nn, const orc_gpu_camera *cam, const float ip[16],
+                         const float view[16]) {
+    orc_sphere dummy = {{0, 0, 0, 1}, 0, 0, 0, 0};
+    orc_ctx *c = orc_create(p, &dummy, 1, mt, nm, nd, nn, cam, ip, view);
+    c->triangles = (orc_triangle *)malloc(sizeof(orc_triangle) * (nt ? nt : 1));
+    memcpy(c->triangles, tris, sizeof(orc_triangle) * nt);
+    c->n_triangles = nt;
+    return c;
+}
+
 void orc_destroy(orc_ctx *c) {
     if (!c) return;
-    free(c->spheres); free(c->materials); free(c->nodes); free(c->rays); free(c->ext_rays); free(c->hits);
+    free(c->spheres); free(c->triangles); free(c->materials); free(c->nodes); free(c->rays); free(c->ext_rays); free(c->hits);
     free(c->misses); free(c->trace_out); free(c->trace_flag); free(c->image); free(c->accumulated);
     free(c);
 }
@@ -605,6 +687,35 @@ static int hit_sphere(const orc_ctx *c, const orc_ray *ray, uint32_t sphere_idx,
     return 0;
 }
 
+/* Build extension (no reference code): Moeller-Trumbore with the same (t_min, t_nearest) window as ex:185-210.
+ * Fixed evaluation order, no fused operations; a degenerate triangle (det == 0) yields inf/NaN barycentrics
+ * and is rejected by the negated range tests. payload.sphere_idx carries the triangle index. */
+static v3 cross3(v3 a, v3 b) { return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static int hit_triangle(const orc_ctx *c, const orc_ray *ray, uint32_t tri_idx, float t_min, float t_nearest,
+                        orc_hit_payload *payload) {
+    const orc_triangle *tr = &c->triangles[tri_idx];
+    v3 d = v3_make(ray->direction[0], ray->direction[1], ray->direction[2]);
+    v3 e1 = v3_make(tr->e1[0], tr->e1[1], tr->e1[2]), e2 = v3_make(tr->e2[0], tr->e2[1], tr->e2[2]);
+    v3 pvec = cross3(d, e2);
+    float det = v3_dot(e1, pvec);
+    float inv_det = 1.0f / det;
+    v3 tvec = v3_make(ray->origin[0] - tr->v0[0], ray->origin[1] - tr->v0[1], ray->origin[2] - tr->v0[2]);
+    float u = v3_dot(tvec, pvec) * inv_det;
+    if (!(u >= 0.0f && u <= 1.0f)) return 0;
+    v3 qvec = cross3(tvec, e1);
+    float v = v3_dot(d, qvec) * inv_det;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
+    float t = v3_dot(e2, qvec) * inv_det;
+    if (t > t_min && t < t_nearest) {
+        payload->t = t; payload->ray_idx = 0; payload->sphere_idx = tri_idx; payload->mat_type = tr->material_type;
+        return 1;
+    }
+    return 0;
+}
+static int hit_prim(const orc_ctx *c, const orc_ray *ray, uint32_t idx, float t_min, float t_nearest, orc_hit_payload *p) {
+    return c->triangles ? hit_triangle(c, ray, idx, t_min, t_nearest, p) : hit_sphere(c, ray, idx, t_min, t_nearest, p);
+}
+
 /* ex:164-183 */
 static float hit_bvh_node(const orc_bvh_node *node, const orc_ray *ray, float nearest_hit) {
     float t_x_min = (node->aabb_min[0] - ray->origin[0]) * ray->inv_direction[0];
@@ -641,7 +752,7 @@ static int trace_ray_bvh(const orc_ctx *c, const orc_ray *ray, orc_hit_payload *
             for (uint32_t i = 0; i < node.prim_count; i++) {
                 orc_hit_payload nh;
                 st->tests++;
-                if (hit_sphere(c, ray, node.left_first + i, 0.001f, nearest_hit, &nh)) {
+                if (hit_prim(c, ray, node.left_first + i, 0.001f, nearest_hit, &nh)) {
                     nearest_hit = nh.t;
                     temp = nh;
                 }
@@ -682,9 +793,10 @@ int orc_trace_brute(const orc_ctx *c, const orc_ray *ray, orc_hit_payload *out) 
     float nearest_hit = 1e30f;
     orc_hit_payload temp;
     memset(&temp, 0, sizeof temp);
-    for (uint32_t i = 0; i < c->n_spheres; i++) {
+    const uint32_t n_prims = c->triangles ? c->n_triangles : c->n_spheres;
+    for (uint32_t i = 0; i < n_prims; i++) {
         orc_hit_payload nh;
-        if (hit_sphere(c, ray, i, 0.001f, nearest_hit, &nh)) { nearest_hit = nh.t; temp = nh; }
+        if (hit_prim(c, ray, i, 0.001f, nearest_hit, &nh)) { nearest_hit = nh.t; temp = nh; }
     }
     if (nearest_hit < 1e30f) { *out = temp; return 1; }
     return 0;
@@ -810,8 +922,9 @@ void orc_shade(orc_ctx *c, uint32_t gx, uint32_t gy) {
         }
         uint32_t rng_state = orc_init_rng(id_x, id_y, c->frame.width, c->frame.frame); /* sh:71-72 */
         orc_advance(&rng_state, c->frame.sample_number * 10u);                         /* sh:73 */
-        const orc_sphere *sphere = &c->spheres[payload.sphere_idx];
-        uint32_t mat_idx = sphere->material_idx;
+        const orc_sphere *sphere = c->triangles ? NULL : &c->spheres[payload.sphere_idx];
+        const orc_triangle *tri = c->triangles ? &c->triangles[payload.sphere_idx] : NULL;
+        uint32_t mat_idx = tri ? tri->material_idx : sphere->material_idx;
         const orc_material *mat = &c->materials[mat_idx];
         float *px = &c->image[3 * (size_t)local_pixel(c, pixel_idx)];
         px[0] = px[0] * mat->albedo[0]; /* sh:84-87 */
@@ -821,9 +934,14 @@ void orc_shade(orc_ctx *c, uint32_t gx, uint32_t gy) {
         /* sh:91-93: p = origin + t * direction (vec4), n = normalize(p - center).xyz */
         v4 p = {ray->origin[0] + payload.t * ray->direction[0], ray->origin[1] + payload.t * ray->direction[1],
                 ray->origin[2] + payload.t * ray->direction[2], ray->origin[3] + payload.t * ray->direction[3]};
-        v4 pc = {p.x - sphere->center[0], p.y - sphere->center[1], p.z - sphere->center[2], p.w - sphere->center[3]};
-        v4 n4 = v4_normalize(pc);
-        v3 nrm = v3_make(n4.x, n4.y, n4.z);
+        v3 nrm;
+        if (tri) { /* build extension: geometric normal of the winding, normalize(cross(e1, e2)), never flipped */
+            nrm = v3_normalize(cross3(v3_make(tri->e1[0], tri->e1[1], tri->e1[2]), v3_make(tri->e2[0], tri->e2[1], tri->e2[2])));
+        } else {
+            v4 pc = {p.x - sphere->center[0], p.y - sphere->center[1], p.z - sphere->center[2], p.w - sphere->center[3]};
+            v4 n4 = v4_normalize(pc);
+            nrm = v3_make(n4.x, n4.y, n4.z);
+        }
         v3 rdir = v3_make(ray->direction[0], ray->direction[1], ray->direction[2]);
         v3 ext_dir = v3_make(0.0f, 0.0f, 0.0f);
         if (mat_type == 1u) { /* sh:110-114 */

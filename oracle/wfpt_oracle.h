@@ -34,6 +34,9 @@ typedef struct { float aabb_min[3]; uint32_t left_first; float aabb_max[3]; uint
 typedef struct { float position[4]; float pitch, yaw, defocus_radius, focus_distance; } orc_gpu_camera;
 /* wavefront_common/src/gpu_structs.rs:5-12, generate_rays.wgsl:21-26 -- 16 B */
 typedef struct { uint32_t width, height, frame, sample_number; } orc_frame_buffer;
+/* Build extension (the reference has spheres only, README.md:22-26 lists other shapes as future work):
+ * triangle as vertex + two edges -- 48 B */
+typedef struct { float v0[3]; uint32_t material_idx; float e1[3]; uint32_t material_type; float e2[3]; uint32_t _pad; } orc_triangle;
 /* extend.wgsl:17-22 (device layout) -- 48 B */
 typedef struct { float origin[4]; float direction[4]; float inv_direction[3]; uint32_t pixel_idx; } orc_ray;
 /* extend.wgsl:24-29 -- 16 B */
@@ -61,6 +64,10 @@ uint32_t orc_scene_new(orc_sphere *spheres, orc_material *materials);
 uint32_t orc_scene_book_one_final(uint64_t seed, orc_sphere *spheres, orc_material *materials);
 /* bvh.rs:147-210: reorders spheres in place, writes <= 2*n nodes (n >= 1), returns node count */
 uint32_t orc_build_bvh(orc_sphere *spheres, uint32_t n, orc_bvh_node *nodes);
+/* build extension: the bvh.rs builder over triangles with n_bins bins per axis */
+uint32_t orc_build_bvh_triangles(orc_triangle *tris, uint32_t n, orc_bvh_node *nodes, uint32_t n_bins);
+/* BASELINE config 5: seeded random triangle soup; writes n triangles and 3 materials, returns 3 */
+uint32_t orc_scene_random_mesh(uint64_t seed, uint32_t n, orc_triangle *tris, orc_material *materials);
 /* camera.rs:11-24 */
 void     orc_camera_new(const float look_from[3], const float look_at[3], float *pitch, float *yaw);
 /* camera.rs:41-69: 16 floats, column-major (4 columns of 4) */
@@ -89,6 +96,10 @@ orc_ctx *orc_create(const orc_params *p,
                     const orc_material *materials, uint32_t n_materials,
                     const orc_bvh_node *nodes, uint32_t n_nodes,
                     const orc_gpu_camera *camera, const float inv_proj[16], const float view[16]);
+orc_ctx *orc_create_mesh(const orc_params *p, const orc_triangle *tris, uint32_t n_tris,
+                         const orc_material *materials, uint32_t n_materials,
+                         const orc_bvh_node *nodes, uint32_t n_nodes,
+                         const orc_gpu_camera *camera, const float inv_proj[16], const float view[16]);
 void     orc_destroy(orc_ctx *);
 void     orc_set_frame(orc_ctx *, const orc_frame_buffer *);
 void     orc_set_counters(orc_ctx *, const uint32_t c[16]);

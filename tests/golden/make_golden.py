@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import oracle as O  # noqa: E402
-from helpers import inputs_for, make_oracle  # noqa: E402
+from helpers import inputs_for, make_mesh_oracle, make_oracle, mesh_inputs  # noqa: E402
 
 
 def sha(a):
@@ -83,5 +83,17 @@ def main():
             print(w, h, mode, case["acc_sha256"][:16], case["totals"])
 
 
+def mesh_golden():
+    # (4) build extension: triangle soup, 5000 triangles with 8x edges, both RNG modes
+    w, h, spp, bounces = 200, 120, 2, 6
+    for mode in (0, 1):
+        o = make_mesh_oracle(O, mesh_inputs(O, w, h, 5000, 8.0), w, h, max_wavefronts=bounces, rng_mode=mode)
+        acc = o.render(spp)
+        np.savez_compressed(os.path.join(HERE, f"mesh5000_200x120_mode{mode}.npz"), width=w, height=h, spp=spp, bounces=bounces,
+                            table=o.bounce_table(), totals=o.totals(), acc_sha256=sha(acc), acc=acc)
+        o.close()
+
+
 if __name__ == "__main__":
+    mesh_golden()
     main()

@@ -38,3 +38,28 @@ def inputs_for(O, kind, width, height, seed=1):
 
 def sorted_rays(r):
     return np.sort(r, order=["pixel_idx"])
+
+
+def mesh_inputs(O, width, height, n_triangles, edge_scale=1.0, seed=1, n_bins=32):
+    """BASELINE config 5's triangle soup (optionally with longer edges so that small meshes get hit)."""
+    tris, mt = O.scene_random_mesh(n_triangles, seed)
+    if edge_scale != 1.0:
+        tris["e1"] *= np.float32(edge_scale)
+        tris["e2"] *= np.float32(edge_scale)
+    tris, nodes = O.build_bvh_triangles(tris, n_bins)
+    cam, ip, vw = O.mesh_camera(width, height)
+    return tris, mt, nodes, cam, ip, vw
+
+
+def make_mesh_oracle(O, inputs, width, height, **kw):
+    tris, mt, nodes, cam, ip, vw = inputs
+    return O.Oracle(width, height, np.zeros(1, O.SPHERE), mt, nodes, cam, ip, vw, triangles=tris, **kw)
+
+
+def make_mesh_tracer(W, width, height, n_triangles, edge_scale=1.0, seed=1, n_bins=32, **kw):
+    scene = W.Scene.random_mesh(n_triangles, seed)
+    if edge_scale != 1.0:
+        scene.triangles["e1"] *= np.float32(edge_scale)
+        scene.triangles["e2"] *= np.float32(edge_scale)
+    cc = W.CameraController(W.Camera((0.0, 0.0, 30.0), (0.0, 0.0, 0.0)), 40.0, 0.0, 10.0, 0.1, 100.0)
+    return W.PathTracer(scene, W.RenderParameters(cc, (width, height)), mesh_bins=n_bins, **kw)

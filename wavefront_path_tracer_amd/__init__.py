@@ -49,6 +49,9 @@ GPU_CAMERA = np.dtype([("position", "<f4", 4), ("pitch", "<f4"), ("yaw", "<f4"),
 RAY = np.dtype([("origin", "<f4", 4), ("direction", "<f4", 4), ("inv_direction", "<f4", 3),
                 ("pixel_idx", "<u4")])
 HIT = np.dtype([("t", "<f4"), ("ray_idx", "<u4"), ("sphere_idx", "<u4"), ("mat_type", "<u4")])
+# build extension (the reference has spheres only): vertex + two edges, 48 B
+TRIANGLE = np.dtype([("v0", "<f4", 3), ("material_idx", "<u4"), ("e1", "<f4", 3), ("material_type", "<u4"),
+                     ("e2", "<f4", 3), ("_pad", "<u4")])
 
 
 class WfptError(RuntimeError):
@@ -102,6 +105,9 @@ def lib():
         "wfpt_scene_new": (u32, [vp, vp]),
         "wfpt_scene_book_one_final": (u32, [C.c_uint64, vp, vp, u32]),
         "wfpt_build_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32)]),
+        "wfpt_build_bvh_triangles": (i32, [vp, u32, vp, u32, C.POINTER(u32), u32]),
+        "wfpt_scene_random_mesh": (u32, [C.c_uint64, u32, vp, vp]),
+        "wfpt_create_mesh": (vp, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]),
         "wfpt_camera_new": (None, [vp, vp, C.POINTER(f32), C.POINTER(f32)]),
         "wfpt_view_transform": (None, [vp, f32, f32, vp]),
         "wfpt_p_inv": (None, [f32, f32, f32, f32, vp]),
@@ -206,9 +212,17 @@ def selftest_math(op, a, b=None, device=0):
 class Scene:
     """wavefront_common/src/scene.rs: `spheres` and `materials` in the reference's 32-byte layouts."""
 
-    def __init__(self, spheres, materials):
+    def __init__(self, spheres, materials, triangles=None):
         self.spheres = np.ascontiguousarray(spheres, SPHERE)
         self.materials = np.ascontiguousarray(materials, MATERIAL)
+        self.triangles = None if triangles is None else np.ascontiguousarray(triangles, TRIANGLE)  # build extension
+
+    @classmethod
+    def random_mesh(cls, n_triangles, seed=1):
+        """BASELINE config 5's seeded triangle soup (build extension: the reference has no triangle type)."""
+        tr, mt = np.zeros(n_triangles, TRIANGLE), np.zeros(3, MATERIAL)
+        lib().wfpt_scene_random_mesh(seed, n_triangles, _p(tr), _p(mt))
+        return cls(np.zeros(0, SPHERE), mt, tr)
 
     @classmethod
     def new(cls):
@@ -243,6 +257,17 @@ class BVHTree:
         st = lib().wfpt_build_bvh(_p(spheres), len(spheres), _p(nodes), len(nodes), C.byref(n))
         if st != 0:
             raise WfptError(st, "wfpt_build_bvh failed")
+        self.nodes = nodes[:n.value].copy()
+
+    def build_bvh_tree_triangles(self, triangles, n_bins=32):
+        """Build extension: the same builder over a TRIANGLE array (reordered in place), n_bins bins per axis."""
+        if not (isinstance(triangles, np.ndarray) and triangles.dtype == TRIANGLE and triangles.flags.c_contiguous):
+            raise TypeError("triangles must be a contiguous TRIANGLE array (it is reordered in place)")
+        nodes = np.zeros(self.capacity, BVH_NODE)
+        n = C.c_uint32()
+        st = lib().wfpt_build_bvh_triangles(_p(triangles), len(triangles), _p(nodes), len(nodes), C.byref(n), n_bins)
+        if st != 0:
+            raise WfptError(st, "wfpt_build_bvh_triangles failed")
         self.nodes = nodes[:n.value].copy()
 
 
@@ -403,7 +428,7 @@ class PathTracer:
     counter read-backs; `render(spp)` is the same loop resident on the device (no host synchronisation)."""
 
     def __init__(self, scene, rp, max_window_size=0, max_wavefronts=50, miss_floor=128, rng_mode=RNG_DISPATCH,
-                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0):
+                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0, mesh_bins=32):
         L = lib()
         self.handle = None
         self.scene = scene
@@ -411,8 +436,12 @@ class PathTracer:
         self.render_progress = RenderProgress()
         self.spp = spp
         self.max_wavefronts, self.miss_floor = max_wavefronts, miss_floor
-        bvh = BVHTree(len(scene.spheres))
-        bvh.build_bvh_tree(scene.spheres)  # path_tracer.rs:117-118
+        if scene.triangles is not None:
+            bvh = BVHTree(len(scene.triangles))
+            bvh.build_bvh_tree_triangles(scene.triangles, mesh_bins)
+        else:
+            bvh = BVHTree(len(scene.spheres))
+            bvh.build_bvh_tree(scene.spheres)  # path_tracer.rs:117-118
         self.bvh_tree = bvh
         cc = rp.camera_controller()
         w, h = rp.viewport_size()
@@ -424,9 +453,14 @@ class PathTracer:
         cam = cc.get_GPU_camera()
         self._params = _Params(w, h, max_window_size, max_wavefronts, miss_floor, rng_mode, flags,
                                tile_rank, tile_world, device, batch)
-        self.handle = L.wfpt_create(C.byref(self._params), _p(scene.spheres), len(scene.spheres),
-                                    _p(scene.materials), len(scene.materials), _p(bvh.nodes), len(bvh.nodes),
-                                    _p(cam), _p(proj), _p(view))
+        if scene.triangles is not None:
+            self.handle = L.wfpt_create_mesh(C.byref(self._params), _p(scene.triangles), len(scene.triangles),
+                                             _p(scene.materials), len(scene.materials), _p(bvh.nodes), len(bvh.nodes),
+                                             _p(cam), _p(proj), _p(view))
+        else:
+            self.handle = L.wfpt_create(C.byref(self._params), _p(scene.spheres), len(scene.spheres),
+                                        _p(scene.materials), len(scene.materials), _p(bvh.nodes), len(bvh.nodes),
+                                        _p(cam), _p(proj), _p(view))
         if not self.handle:
             raise WfptError(-2, L.wfpt_last_error(None).decode())
         self.n_pixels = L.wfpt_n_pixels(self.handle)
@@ -623,4 +657,11 @@ def shirley_path_tracer(width, height, seed=1, **kw):
     """main.rs:17-36: seeded Shirley scene, book camera (13,2,3)->origin, vfov 20, defocus 0.6, focus 10."""
     scene = Scene.book_one_final(seed)
     cc = CameraController(Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
+    return PathTracer(scene, RenderParameters(cc, (width, height)), **kw)
+
+
+def mesh_path_tracer(width, height, n_triangles, seed=1, **kw):
+    """BASELINE config 5: seeded triangle soup, camera (0,0,30) -> origin, vfov 40, no defocus."""
+    scene = Scene.random_mesh(n_triangles, seed)
+    cc = CameraController(Camera((0.0, 0.0, 30.0), (0.0, 0.0, 0.0)), 40.0, 0.0, 10.0, 0.1, 100.0)
     return PathTracer(scene, RenderParameters(cc, (width, height)), **kw)

@@ -53,10 +53,12 @@ struct wfpt_ctx {
     wfpt_bvh_node *d_nodes = nullptr;
     float4 *d_sphere_geom = nullptr;
     uint16_t *d_pair_parent = nullptr;
+    uint32_t *d_pair_parent32 = nullptr;
     wfpt_sphere *d_spheres = nullptr;
+    wfpt_triangle *d_triangles = nullptr;
     wfpt_material *d_materials = nullptr;
     SceneDev scene{};
-    std::vector<wfpt_sphere> h_spheres;
+    std::vector<uint32_t> h_prim_mat_type; // material_type per primitive, for wfpt_read_hits (extend.wgsl:199)
 
     uint32_t accumulate_grid = 0;
     uint32_t progress_frame = 0, accumulated_samples = 0;
@@ -112,8 +114,8 @@ void set_viewport(wfpt_ctx *c, uint32_t w, uint32_t h) {
 // The traversal needs siblings at (2k, 2k+1), which BVHTree::subdivide guarantees (bvh.rs:160-161,
 // 191-206), and at most 63 levels. Returns the tree depth or a negative status.
 int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint32_t n_spheres,
-                 std::vector<uint16_t> &pair_parent) {
-    if (n_nodes == 0 || n_nodes > 65536u) return fail(c, WFPT_ERR_UNSUPPORTED, "BVH must have 1..65536 nodes");
+                 std::vector<uint32_t> &pair_parent) {
+    if (n_nodes == 0 || n_nodes > (1u << 30)) return fail(c, WFPT_ERR_UNSUPPORTED, "BVH must have 1..2^30 nodes");
     pair_parent.assign(((n_nodes / 2u + 1u) + 7u) / 8u * 8u, 0);
     std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
     uint32_t max_depth = 0, visited = 0;
@@ -130,7 +132,7 @@ int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint
             const uint32_t l = nd.left_first;
             if (l < 2 || (l & 1u) || l + 1 >= n_nodes)
                 return fail(c, WFPT_ERR_UNSUPPORTED, "BVH children must sit at (2k, 2k+1), k >= 1 (bvh.rs layout)");
-            pair_parent[l >> 1] = static_cast<uint16_t>(i);
+            pair_parent[l >> 1] = i;
             todo.push_back({l, d + 1});
             todo.push_back({l + 1, d + 1});
         }
@@ -429,10 +431,11 @@ int wfpt_device_count(void) {
 
 const char *wfpt_last_error(const wfpt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
-wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uint32_t n_spheres,
-                      const wfpt_material *materials, uint32_t n_materials, const wfpt_bvh_node *nodes,
-                      uint32_t n_nodes, const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]) {
-    if (!params || !spheres || !materials || !nodes || !camera || !inv_proj || !view || n_spheres == 0 ||
+static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spheres, const wfpt_triangle *triangles,
+                             uint32_t n_spheres, const wfpt_material *materials, uint32_t n_materials,
+                             const wfpt_bvh_node *nodes, uint32_t n_nodes, const wfpt_gpu_camera *camera,
+                             const float inv_proj[16], const float view[16]) {
+    if (!params || !(spheres || triangles) || !materials || !nodes || !camera || !inv_proj || !view || n_spheres == 0 ||
         n_materials == 0 || params->width == 0 || params->height == 0) {
         fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: null or empty argument");
         return nullptr;
@@ -446,8 +449,8 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
         return nullptr;
     }
     for (uint32_t i = 0; i < n_spheres; ++i)
-        if (spheres[i].material_idx >= n_materials) {
-            fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: sphere material_idx out of range");
+        if ((spheres ? spheres[i].material_idx : triangles[i].material_idx) >= n_materials) {
+            fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: primitive material_idx out of range");
             return nullptr;
         }
     int n_dev = 0;
@@ -465,7 +468,7 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
         delete c;
         return nullptr;
     }
-    std::vector<uint16_t> pair_parent;
+    std::vector<uint32_t> pair_parent;
     const int bvh_depth = validate_bvh(c, nodes, n_nodes, n_spheres, pair_parent);
     if (bvh_depth < 0) {
         g_last_error = c->err;
@@ -526,37 +529,54 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control) * kMaxBatch, c->stream));
     CREATE_HIP(dmalloc(&c->camera, 1));
 
-    // scene upload (pt:120-128) plus the traversal's LDS-friendly copies
-    c->h_spheres.assign(spheres, spheres + n_spheres);
-    std::vector<float4> geom(n_spheres);
+    // scene upload (pt:120-128) plus the traversal's copies: primitive geometry and the sibling-pair parent table
+    const uint32_t prim_kind = triangles ? 1u : 0u;
+    c->h_prim_mat_type.resize(n_spheres);
     for (uint32_t i = 0; i < n_spheres; ++i)
-        geom[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
+        c->h_prim_mat_type[i] = spheres ? spheres[i].material_type : triangles[i].material_type;
     CREATE_HIP(dmalloc(&c->d_nodes, n_nodes));
-    CREATE_HIP(dmalloc(&c->d_sphere_geom, n_spheres));
-    CREATE_HIP(dmalloc(&c->d_pair_parent, pair_parent.size()));
-    CREATE_HIP(dmalloc(&c->d_spheres, n_spheres));
     CREATE_HIP(dmalloc(&c->d_materials, n_materials));
     CREATE_HIP(hipMemcpy(c->d_nodes, nodes, sizeof(wfpt_bvh_node) * n_nodes, hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(c->d_sphere_geom, geom.data(), sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(c->d_pair_parent, pair_parent.data(), sizeof(uint16_t) * pair_parent.size(), hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(c->d_spheres, spheres, sizeof(wfpt_sphere) * n_spheres, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(c->d_materials, materials, sizeof(wfpt_material) * n_materials, hipMemcpyHostToDevice));
+    if (spheres) {
+        std::vector<float4> geom(n_spheres);
+        for (uint32_t i = 0; i < n_spheres; ++i)
+            geom[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
+        CREATE_HIP(dmalloc(&c->d_sphere_geom, n_spheres));
+        CREATE_HIP(dmalloc(&c->d_spheres, n_spheres));
+        CREATE_HIP(hipMemcpy(c->d_sphere_geom, geom.data(), sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
+        CREATE_HIP(hipMemcpy(c->d_spheres, spheres, sizeof(wfpt_sphere) * n_spheres, hipMemcpyHostToDevice));
+        c->scene.prim_geom = c->d_sphere_geom;
+    } else {
+        CREATE_HIP(dmalloc(&c->d_triangles, n_spheres));
+        CREATE_HIP(hipMemcpy(c->d_triangles, triangles, sizeof(wfpt_triangle) * n_spheres, hipMemcpyHostToDevice));
+        c->scene.prim_geom = reinterpret_cast<const float4 *>(c->d_triangles); // 3 x float4 per triangle
+    }
+    // LDS variant when nodes + primitives + parents fit comfortably (>= 2 workgroups per CU); otherwise the
+    // scene stays in HBM / Infinity Cache and extend reads it through L2.
+    const uint32_t lds_need = extend_lds_bytes(n_nodes, n_spheres, prim_kind, true);
+    const bool lds_scene = n_nodes <= 65536u && lds_need <= 80u * 1024u;
+    if (lds_scene) {
+        std::vector<uint16_t> p16(pair_parent.begin(), pair_parent.end());
+        CREATE_HIP(dmalloc(&c->d_pair_parent, p16.size()));
+        CREATE_HIP(hipMemcpy(c->d_pair_parent, p16.data(), sizeof(uint16_t) * p16.size(), hipMemcpyHostToDevice));
+    } else {
+        CREATE_HIP(dmalloc(&c->d_pair_parent32, pair_parent.size()));
+        CREATE_HIP(hipMemcpy(c->d_pair_parent32, pair_parent.data(), sizeof(uint32_t) * pair_parent.size(), hipMemcpyHostToDevice));
+    }
     c->scene.nodes = c->d_nodes;
-    c->scene.sphere_geom = c->d_sphere_geom;
     c->scene.pair_parent = c->d_pair_parent;
+    c->scene.pair_parent32 = c->d_pair_parent32;
     c->scene.spheres = c->d_spheres;
+    c->scene.triangles = c->d_triangles;
     c->scene.materials = c->d_materials;
     c->scene.n_nodes = n_nodes;
     c->scene.n_spheres = n_spheres;
     c->scene.n_materials = n_materials;
-    c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres);
+    c->scene.prim_kind = prim_kind;
+    c->scene.lds_scene = lds_scene ? 1u : 0u;
+    c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres, prim_kind, lds_scene);
     c->scene.depth = static_cast<uint32_t>(bvh_depth);
-    if (c->scene.lds_bytes > 160u * 1024u) {
-        fail(c, WFPT_ERR_UNSUPPORTED, "scene does not fit the 160 KiB LDS of a gfx950 CU");
-        g_last_error = c->err;
-        wfpt_destroy(c);
-        return nullptr;
-    }
 
     CameraDev cam{};
     cam.cam = *camera;
@@ -569,7 +589,7 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
     int blocks_per_cu = 1;
-    CREATE_HIP(extend_blocks_per_cu(c->scene.lds_bytes, &blocks_per_cu));
+    CREATE_HIP(extend_blocks_per_cu(c->scene, &blocks_per_cu));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     const uint32_t cus = static_cast<uint32_t>(prop.multiProcessorCount);
     c->cus = cus;
@@ -579,6 +599,26 @@ wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uin
     CREATE_HIP(hipStreamSynchronize(c->stream));
 #undef CREATE_HIP
     return c;
+}
+
+wfpt_ctx *wfpt_create(const wfpt_params *params, const wfpt_sphere *spheres, uint32_t n_spheres,
+                      const wfpt_material *materials, uint32_t n_materials, const wfpt_bvh_node *nodes,
+                      uint32_t n_nodes, const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]) {
+    if (!spheres) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: null or empty argument");
+        return nullptr;
+    }
+    return create_impl(params, spheres, nullptr, n_spheres, materials, n_materials, nodes, n_nodes, camera, inv_proj, view);
+}
+
+wfpt_ctx *wfpt_create_mesh(const wfpt_params *params, const wfpt_triangle *triangles, uint32_t n_triangles,
+                           const wfpt_material *materials, uint32_t n_materials, const wfpt_bvh_node *nodes,
+                           uint32_t n_nodes, const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]) {
+    if (!triangles) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create_mesh: null or empty argument");
+        return nullptr;
+    }
+    return create_impl(params, nullptr, triangles, n_triangles, materials, n_materials, nodes, n_nodes, camera, inv_proj, view);
 }
 
 void wfpt_destroy(wfpt_ctx *c) {
@@ -593,7 +633,8 @@ void wfpt_destroy(wfpt_ctx *c) {
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
     void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_t, c->hit_prim, c->hit_ridx, c->miss_ridx, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->image, c->accumulated, c->ctl, c->camera,
-                    c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_spheres, c->d_materials};
+                    c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,
+                    c->d_materials};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -868,7 +909,7 @@ int wfpt_read_hits(wfpt_ctx *c, wfpt_hit_payload *out, uint32_t n) {
         out[pos].t = t;
         out[pos].ray_idx = ridx;
         out[pos].sphere_idx = prim;
-        out[pos].mat_type = prim < c->h_spheres.size() ? c->h_spheres[prim].material_type : 0u; // ex:199
+        out[pos].mat_type = prim < c->h_prim_mat_type.size() ? c->h_prim_mat_type[prim] : 0u; // ex:199
     });
 }
 

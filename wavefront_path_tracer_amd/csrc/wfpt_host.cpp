@@ -69,7 +69,7 @@ wfpt_material metal(Vec3 a, float fuzz) {                                       
 wfpt_material dielectric(float ri) { return make_material({1.0f, 1.0f, 1.0f}, 0.0f, ri, 2); } // material.rs:34-36
 
 // ---- BVH builder (wc/bvh.rs) ----
-constexpr int kBins = 4096; // bvh.rs:4
+constexpr int kReferenceBins = 4096; // bvh.rs:4
 
 struct Aabb {
     Vec3 lo{kInf, kInf, kInf}, hi{-kInf, -kInf, -kInf};
@@ -86,9 +86,30 @@ inline void sphere_bounds(const wfpt_sphere &s, Vec3 &lo, Vec3 &hi) { // sphere.
     hi = {s.center[0] + s.radius, s.center[1] + s.radius, s.center[2] + s.radius};
 }
 
-class BvhBuilder {
+// What bvh.rs needs from a primitive: its box, the coordinate it is binned and partitioned by, a swap.
+struct SpherePrims {
+    wfpt_sphere *p;
+    void bounds(uint32_t i, Vec3 &lo, Vec3 &hi) const { sphere_bounds(p[i], lo, hi); }
+    float key(uint32_t i, int axis) const { return p[i].center[axis]; } // bvh.rs:97,179: the sphere's centre
+    void swap(long long i, long long j) const { std::swap(p[i], p[j]); }
+};
+struct TrianglePrims { // build extension
+    wfpt_triangle *p;
+    void bounds(uint32_t i, Vec3 &lo, Vec3 &hi) const {
+        const wfpt_triangle &t = p[i];
+        const Vec3 a{t.v0[0], t.v0[1], t.v0[2]};
+        const Vec3 b{t.v0[0] + t.e1[0], t.v0[1] + t.e1[1], t.v0[2] + t.e1[2]};
+        const Vec3 c{t.v0[0] + t.e2[0], t.v0[1] + t.e2[1], t.v0[2] + t.e2[2]};
+        lo = vmin(vmin(a, b), c);
+        hi = vmax(vmax(a, b), c);
+    }
+    float key(uint32_t i, int axis) const { return p[i].v0[axis] + (p[i].e1[axis] + p[i].e2[axis]) * 0.33333334f; }
+    void swap(long long i, long long j) const { std::swap(p[i], p[j]); }
+};
+
+template <typename Prims> class BvhBuilder {
   public:
-    BvhBuilder(wfpt_sphere *spheres, wfpt_bvh_node *nodes) : spheres_(spheres), nodes_(nodes) {
+    BvhBuilder(Prims prims, wfpt_bvh_node *nodes, int n_bins) : spheres_(prims), nodes_(nodes), kBins(n_bins) {
         bins_.resize(kBins);
         bin_count_.resize(kBins);
         left_count_.resize(kBins - 1);
@@ -113,7 +134,7 @@ class BvhBuilder {
         Aabb box;
         for (uint32_t i = 0; i < nd.prim_count; ++i) {
             Vec3 lo, hi;
-            sphere_bounds(spheres_[nd.left_first + i], lo, hi);
+            spheres_.bounds(nd.left_first + i, lo, hi);
             box.grow(lo, hi);
         }
         nd.aabb_min[0] = box.lo.x; nd.aabb_min[1] = box.lo.y; nd.aabb_min[2] = box.lo.z;
@@ -132,13 +153,12 @@ class BvhBuilder {
             const float scale = static_cast<float>(kBins) / extent[axis];
             const float lo_bound = nd.aabb_min[axis];
             for (uint32_t i = 0; i < nd.prim_count; ++i) {
-                const wfpt_sphere &s = spheres_[nd.left_first + i];
-                const float pos = (s.center[axis] - lo_bound) * scale;
+                const float pos = (spheres_.key(nd.left_first + i, axis) - lo_bound) * scale;
                 // Rust `as usize` saturates (negative/NaN -> 0), then .min(BINS - 1)
                 long long b = pos > 0.0f ? (pos >= 2147483648.0f ? 2147483647LL : static_cast<long long>(pos)) : 0;
                 if (b > kBins - 1) b = kBins - 1;
                 Vec3 lo, hi;
-                sphere_bounds(s, lo, hi);
+                spheres_.bounds(nd.left_first + i, lo, hi);
                 bins_[b].grow(lo, hi);
                 bin_count_[b] += 1;
             }
@@ -181,10 +201,10 @@ class BvhBuilder {
         long long i = nodes_[index].left_first;
         long long j = i + static_cast<long long>(nodes_[index].prim_count) - 1;
         while (i <= j) {
-            if (spheres_[i].center[split.axis] < split.plane) {
+            if (spheres_.key(static_cast<uint32_t>(i), split.axis) < split.plane) {
                 ++i;
             } else {
-                std::swap(spheres_[i], spheres_[j]);
+                spheres_.swap(i, j);
                 --j;
             }
         }
@@ -207,8 +227,9 @@ class BvhBuilder {
         subdivide(child + 1);
     }
 
-    wfpt_sphere *spheres_;
+    Prims spheres_; // named after bvh.rs's `spheres` argument
     wfpt_bvh_node *nodes_;
+    const int kBins;
     uint32_t count_ = 0;
     std::vector<Aabb> bins_;
     std::vector<uint32_t> bin_count_, left_count_, right_count_;
@@ -278,9 +299,40 @@ uint32_t wfpt_scene_book_one_final(uint64_t seed, wfpt_sphere *sp, wfpt_material
 int wfpt_build_bvh(wfpt_sphere *spheres, uint32_t n, wfpt_bvh_node *nodes, uint32_t cap, uint32_t *n_nodes) {
     if (!spheres || !nodes || !n_nodes || n == 0) return WFPT_ERR_INVALID_ARGUMENT;
     if (cap < 2 * n) return WFPT_ERR_INVALID_ARGUMENT; // BVHTree::new reserves 2*n (bvh.rs:148-150)
-    BvhBuilder builder(spheres, nodes);
+    BvhBuilder<SpherePrims> builder(SpherePrims{spheres}, nodes, kReferenceBins);
     *n_nodes = builder.build(n);
     return WFPT_OK;
+}
+
+int wfpt_build_bvh_triangles(wfpt_triangle *tris, uint32_t n, wfpt_bvh_node *nodes, uint32_t cap, uint32_t *n_nodes,
+                             uint32_t n_bins) {
+    if (!tris || !nodes || !n_nodes || n == 0) return WFPT_ERR_INVALID_ARGUMENT;
+    if (cap < 2 * n || n_bins > (1u << 20)) return WFPT_ERR_INVALID_ARGUMENT;
+    BvhBuilder<TrianglePrims> builder(TrianglePrims{tris}, nodes, static_cast<int>(n_bins < 2 ? 2 : n_bins));
+    *n_nodes = builder.build(n);
+    return WFPT_OK;
+}
+
+uint32_t wfpt_scene_random_mesh(uint64_t seed, uint32_t n, wfpt_triangle *tris, wfpt_material *mt) {
+    SceneRng rng(seed);
+    mt[0] = lambertian({0.7f, 0.7f, 0.7f});
+    mt[1] = metal({0.8f, 0.8f, 0.8f}, 0.1f);
+    mt[2] = dielectric(1.5f);
+    for (uint32_t i = 0; i < n; ++i) {
+        float c[3], e1[3], e2[3];
+        for (float &v : c) v = rng.range(-10.0f, 10.0f);
+        for (float &v : e1) v = rng.range(-0.05f, 0.05f);
+        for (float &v : e2) v = rng.range(-0.05f, 0.05f);
+        wfpt_triangle &t = tris[i];
+        for (int k = 0; k < 3; ++k) {
+            t.v0[k] = c[k] - (e1[k] + e2[k]) * 0.33333334f; // the centre is the centroid
+            t.e1[k] = e1[k];
+            t.e2[k] = e2[k];
+        }
+        t.material_idx = t.material_type = i % 3u;
+        t._pad = 0;
+    }
+    return 3;
 }
 
 void wfpt_camera_new(const float from[3], const float at[3], float *pitch, float *yaw) { // camera.rs:11-24

@@ -56,11 +56,15 @@ struct Control {
 
 struct SceneDev {
     const wfpt_bvh_node *nodes;   // reference layout, 32 B
-    const float4 *sphere_geom;    // (cx, cy, cz, r), 16 B
-    const uint16_t *pair_parent;  // parent node of the sibling pair (2k, 2k+1); padded to 8 entries
+    const float4 *prim_geom;      // spheres: (cx, cy, cz, r), 16 B each; triangles: the wfpt_triangle array, 3 x 16 B each
+    const uint16_t *pair_parent;  // LDS variant: parent node of the sibling pair (2k, 2k+1); padded to 8 entries
+    const uint32_t *pair_parent32; // HBM variant: same table, 32-bit
     const wfpt_sphere *spheres;   // reference layout (shade reads material_idx / material_type)
+    const wfpt_triangle *triangles;
     const wfpt_material *materials;
-    uint32_t n_nodes, n_spheres, n_materials;
+    uint32_t n_nodes, n_spheres, n_materials; // n_spheres = primitive count
+    uint32_t prim_kind;           // 0 spheres (the reference), 1 triangles (build extension)
+    uint32_t lds_scene;           // 1: nodes + primitives + parents are staged in LDS by extend
     uint32_t lds_bytes;           // dynamic LDS the extend kernel needs for this scene
     uint32_t depth;               // levels below the root (validated <= kMaxTrailDepth)
 };
@@ -179,7 +183,7 @@ hipError_t launch_rays_from_aos(const RayQueue &q, const wfpt_ray *in, uint32_t 
 hipError_t launch_selftest_math(int op, const float *a, const float *b, float *out, size_t n, hipStream_t s);
 // Occupancy of the extend kernel for a given dynamic LDS size (workgroups per CU); also raises the
 // kernel's dynamic-LDS limit when the scene needs more than the default 64 KiB.
-hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks);
-uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_spheres);
+hipError_t extend_blocks_per_cu(const SceneDev &scene, int *blocks);
+uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene);
 
 } // namespace wfpt

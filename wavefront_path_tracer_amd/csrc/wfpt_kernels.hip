@@ -177,13 +177,13 @@ __device__ __forceinline__ float4 lds_load4(const float4 *p) {
 // done), then all leaf lanes test their spheres together. Each lane still performs exactly the
 // reference's sequence of operations; only the interleaving across lanes changes, which keeps more lanes
 // active per instruction than alternating leaf/inner work every iteration.
-template <typename Trail>
+template <typename Trail, typename ParentT>
 struct Traversal {
     uint32_t node, left_first, prim_count, depth;
     Trail trail;
 
     // LIFO pop: deepest pending level. Returns false when nothing is pending (ex:95-97, 125-127: break).
-    __device__ __forceinline__ bool pop(const float4 *nodes, const uint16_t *pair_parent) {
+    __device__ __forceinline__ bool pop(const float4 *nodes, const ParentT *pair_parent) {
         if (trail == 0) return false;
         const uint32_t level = (sizeof(Trail) == 8) ? 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(trail)))
                                                     : 31u - static_cast<uint32_t>(__clz(static_cast<int>(trail)));
@@ -197,15 +197,62 @@ struct Traversal {
     }
 };
 
-template <typename Trail>
-__device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *sphere_geom, const uint16_t *pair_parent,
+// Primitive tests. PRIM 0: hit(), ex:185-210 (sphere, half-b quadratic, both roots against the window).
+// PRIM 1 (build extension, no reference code): Moeller-Trumbore in a fixed evaluation order; a degenerate
+// triangle gives inf/NaN barycentrics and fails the negated range tests.
+template <int PRIM>
+__device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float ox, float oy, float oz, float dx, float dy,
+                                         float dz, float a, float &nearest, uint32_t &best) {
+    if (PRIM == 0) {
+        const float4 s = geom[idx];
+        const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+        const float b = (dx * ocx + dy * ocy) + dz * ocz;
+        const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w * s.w;
+        const float discrim = b * b - a * c;
+        if (discrim >= 0.0f) {
+            const float sq = sqrt_(discrim);
+            float t = (-b - sq) / a;
+            if (t > 0.001f && t < nearest) {
+                nearest = t;
+                best = idx;
+            } else {
+                t = (-b + sq) / a;
+                if (t > 0.001f && t < nearest) {
+                    nearest = t;
+                    best = idx;
+                }
+            }
+        }
+    } else {
+        const float4 v0 = geom[3u * idx], e1 = geom[3u * idx + 1u], e2 = geom[3u * idx + 2u];
+        const float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x; // cross(d, e2)
+        const float det = (e1.x * px + e1.y * py) + e1.z * pz;
+        const float inv_det = 1.0f / det;
+        const float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
+        const float u = ((tx * px + ty * py) + tz * pz) * inv_det;
+        if (u >= 0.0f && u <= 1.0f) {
+            const float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x; // cross(tvec, e1)
+            const float v = ((dx * qx + dy * qy) + dz * qz) * inv_det;
+            if (v >= 0.0f && u + v <= 1.0f) {
+                const float t = ((e2.x * qx + e2.y * qy) + e2.z * qz) * inv_det;
+                if (t > 0.001f && t < nearest) {
+                    nearest = t;
+                    best = idx;
+                }
+            }
+        }
+    }
+}
+
+template <typename Trail, int PRIM, typename ParentT>
+__device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *prim_geom, const ParentT *pair_parent,
                                           float ox, float oy, float oz, float dx, float dy, float dz, float &t_out,
                                           uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
     const float a = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
-    Traversal<Trail> tr;
+    Traversal<Trail, ParentT> tr;
     tr.node = 0; // ex:84: the root's box is never tested
     tr.left_first = __float_as_uint(nodes[0].w);
     tr.prim_count = __float_as_uint(nodes[1].w);
@@ -235,27 +282,8 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *sph
         }
         // ---- leaf (ex:86-103)
         if (alive) {
-            for (uint32_t i = 0; i < tr.prim_count; ++i) {
-                const float4 s = sphere_geom[tr.left_first + i]; // hit(), ex:185-210
-                const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-                const float b = (dx * ocx + dy * ocy) + dz * ocz;
-                const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w * s.w;
-                const float discrim = b * b - a * c;
-                if (discrim >= 0.0f) {
-                    const float sq = sqrt_(discrim);
-                    float t = (-b - sq) / a;
-                    if (t > 0.001f && t < nearest) {
-                        nearest = t;
-                        best = tr.left_first + i;
-                    } else {
-                        t = (-b + sq) / a;
-                        if (t > 0.001f && t < nearest) {
-                            nearest = t;
-                            best = tr.left_first + i;
-                        }
-                    }
-                }
-            }
+            for (uint32_t i = 0; i < tr.prim_count; ++i)
+                hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             alive = tr.pop(nodes, pair_parent);
         }
     }
@@ -268,14 +296,18 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *sph
 // segments of 512 rays handed out by an atomic ticket. A segment's hits / misses are compacted in
 // thread order into the matching segment of the hit / miss queues with wave64 ballots + mbcnt and one
 // LDS exchange of the eight per-wave counts; no global atomics on queue slots (ex:59,61 use one per ray).
-template <bool HAS_INACTIVE, typename Trail>
+// LDS_SCENE = false (build extension for scenes larger than a CU's LDS, e.g. BASELINE config 5's 1M-triangle
+// BVH): nodes, primitives and a 32-bit parent table are read from HBM / Infinity Cache through L2 instead.
+template <bool HAS_INACTIVE, typename Trail, int PRIM, bool LDS_SCENE>
 __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
     extern __shared__ float4 lds[];
+    constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u; // float4 per primitive
     float4 *s_nodes = lds;
-    float4 *s_sphere = lds + 2u * a.scene.n_nodes;
-    const uint32_t parent_words = ((a.scene.n_nodes / 2u + 1u) + 7u) / 8u; // uint4 words of 8 u16 entries
-    uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_sphere + a.scene.n_spheres);
-    uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_sphere + a.scene.n_spheres + parent_words);
+    float4 *s_sphere = lds + (LDS_SCENE ? 2u * a.scene.n_nodes : 0u);
+    const uint32_t parent_words = LDS_SCENE ? ((a.scene.n_nodes / 2u + 1u) + 7u) / 8u : 0u; // uint4 words of 8 u16 entries
+    const uint32_t geom_words = LDS_SCENE ? kGeomWords * a.scene.n_spheres : 0u;
+    uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_sphere + geom_words);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_sphere + geom_words + parent_words);
     // s_misc: [2][2][kExtendWaves] wave counts, [2] next work item, [kMaxBatch] rays per sample,
     //         [kMaxBatch + 1] first work item of each sample
     uint32_t *s_next = s_misc + 4 * kExtendWaves;
@@ -297,15 +329,15 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
     const uint32_t n_items = s_first[a.batch.n];
     uint32_t item = blockIdx.x;
     if (item >= n_items) return; // nothing to do: skip the LDS staging too
-    {
-        const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
+    const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
+    if (LDS_SCENE) {
         for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_nodes[i];
-        for (uint32_t i = threadIdx.x; i < a.scene.n_spheres; i += kExtendThreads) s_sphere[i] = a.scene.sphere_geom[i];
+        for (uint32_t i = threadIdx.x; i < geom_words; i += kExtendThreads) s_sphere[i] = a.scene.prim_geom[i];
         const uint4 *g_par = reinterpret_cast<const uint4 *>(a.scene.pair_parent);
         uint4 *s_par4 = reinterpret_cast<uint4 *>(s_parent);
         for (uint32_t i = threadIdx.x; i < parent_words; i += kExtendThreads) s_par4[i] = g_par[i];
+        __syncthreads();
     }
-    __syncthreads();
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t iter = 0;
@@ -330,7 +362,13 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
         float t = 0.0f;
         uint32_t prim = 0;
         bool hit = false;
-        if (live) hit = trace_ray<Trail>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, t, prim);
+        if (live) {
+            if (LDS_SCENE)
+                hit = trace_ray<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, t, prim);
+            else
+                hit = trace_ray<Trail, PRIM, uint32_t>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, ox, oy, oz, dx, dy,
+                                                        dz, t, prim);
+        }
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
         if (lane == 0) {
@@ -513,8 +551,21 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             const float t = a.hq.t[slot];
             const uint32_t prim = a.hq.prim[slot];
             const uint32_t ridx = a.hq.ridx[slot];
-            const wfpt_sphere sph = a.scene.spheres[prim];
-            const uint32_t mat_type = sph.material_type; // == payload.mat_type (ex:199)
+            // primitive record: centre (sphere) or the two edges (triangle), material index and type
+            float c_x = 0.0f, c_y = 0.0f, c_z = 0.0f, e1x = 0.0f, e1y = 0.0f, e1z = 0.0f, e2x = 0.0f, e2y = 0.0f, e2z = 0.0f;
+            uint32_t mat_idx, mat_type; // mat_type == payload.mat_type (ex:199)
+            if (a.scene.prim_kind == 0) {
+                const wfpt_sphere sph = a.scene.spheres[prim];
+                c_x = sph.center[0]; c_y = sph.center[1]; c_z = sph.center[2];
+                mat_idx = sph.material_idx;
+                mat_type = sph.material_type;
+            } else {
+                const wfpt_triangle tri = a.scene.triangles[prim];
+                e1x = tri.e1[0]; e1y = tri.e1[1]; e1z = tri.e1[2];
+                e2x = tri.e2[0]; e2y = tri.e2[1]; e2z = tri.e2[2];
+                mat_idx = tri.material_idx;
+                mat_type = tri.material_type;
+            }
             const bool mine = !filtered || a.material == (mat_type > 2u ? 0u : mat_type);
             if (filtered && a.count_out) { // per-material stage: count only the rays this stage emits
                 const unsigned long long m = __ballot(mine);
@@ -525,7 +576,7 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             const float ox = a.q.ox[ridx], oy = a.q.oy[ridx], oz = a.q.oz[ridx];
             const float dx = a.q.dx[ridx], dy = a.q.dy[ridx], dz = a.q.dz[ridx];
             const uint32_t pixel_idx = a.q.pixel[ridx];
-            const wfpt_material mat = a.scene.materials[sph.material_idx];
+            const wfpt_material mat = a.scene.materials[mat_idx];
 
             // sh:84-87: throughput *= albedo, for every material type
             const uint32_t lp = local_pixel(pixel_idx, a.image_width, a.tile);
@@ -550,7 +601,10 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
 
             // sh:91-93
             const float p_x = ox + t * dx, p_y = oy + t * dy, p_z = oz + t * dz;
-            const float3_ nrm = normalize3({p_x - sph.center[0], p_y - sph.center[1], p_z - sph.center[2]});
+            // spheres: always-outward normal (sh:93); triangles: normalize(cross(e1, e2)), never flipped
+            const float3_ nrm = a.scene.prim_kind == 0
+                                    ? normalize3({p_x - c_x, p_y - c_y, p_z - c_z})
+                                    : normalize3({e1y * e2z - e1z * e2y, e1z * e2x - e1x * e2z, e1x * e2y - e1y * e2x});
             const float3_ rdir = {dx, dy, dz};
             float3_ ext;
             if (mat_type == 1u) { // sh:110-114 metal
@@ -736,30 +790,36 @@ __global__ void selftest_math_kernel(int op, const float *a, const float *b, flo
 // ================================================================================================
 // launchers
 // ================================================================================================
-uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_spheres) {
+uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene) {
+    const uint32_t misc = 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u) + 16u;
+    if (!lds_scene) return misc;
     const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
-    return 32u * n_nodes + 16u * n_spheres + 16u * parent_words + 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u) + 16u;
+    return 32u * n_nodes + 16u * (prim_kind == 0 ? 1u : 3u) * n_prims + 16u * parent_words + misc;
 }
 
 namespace {
 using ExtendFn = void (*)(ExtendArgs);
-ExtendFn extend_variant(bool has_inactive, bool deep) {
-    if (deep) return has_inactive ? extend_kernel<true, unsigned long long> : extend_kernel<false, unsigned long long>;
-    return has_inactive ? extend_kernel<true, uint32_t> : extend_kernel<false, uint32_t>;
+template <bool INACT, int PRIM> ExtendFn extend_pick(bool lds_scene, bool deep) {
+    if (!lds_scene) return extend_kernel<INACT, unsigned long long, PRIM, false>;
+    return deep ? extend_kernel<INACT, unsigned long long, PRIM, true> : extend_kernel<INACT, uint32_t, PRIM, true>;
+}
+ExtendFn extend_variant(const SceneDev &sc, bool has_inactive) {
+    const bool lds = sc.lds_scene != 0, deep = sc.depth > 31u; // a 32-bit trail covers trees up to 31 levels deep
+    if (sc.prim_kind == 0) return has_inactive ? extend_pick<true, 0>(lds, deep) : extend_pick<false, 0>(lds, deep);
+    return has_inactive ? extend_pick<true, 1>(lds, deep) : extend_pick<false, 1>(lds, deep);
 }
 } // namespace
 
-hipError_t extend_blocks_per_cu(uint32_t lds_bytes, int *blocks) {
+hipError_t extend_blocks_per_cu(const SceneDev &scene, int *blocks) {
     hipError_t e = hipSuccess;
-    if (lds_bytes > 64u * 1024u) {
-        for (int v = 0; v < 4; ++v) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_variant(v & 1, v & 2)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (scene.lds_bytes > 64u * 1024u) {
+        for (int v = 0; v < 2; ++v) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_variant(scene, v != 0)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scene.lds_bytes));
             if (e != hipSuccess) return e;
         }
     }
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, extend_kernel<false, unsigned long long>, kExtendThreads,
-                                                        lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, extend_variant(scene, false), kExtendThreads, scene.lds_bytes);
 }
 
 hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
@@ -771,9 +831,7 @@ hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
 
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-    // a 32-bit trail (one pending bit per tree level) is enough for trees up to 31 levels deep
-    hipLaunchKernelGGL(extend_variant(a.has_inactive != 0, a.scene.depth > 31u), dim3(grid), dim3(kExtendThreads),
-                       a.scene.lds_bytes, s, a);
+    hipLaunchKernelGGL(extend_variant(a.scene, a.has_inactive != 0), dim3(grid), dim3(kExtendThreads), a.scene.lds_bytes, s, a);
     return hipGetLastError();
 }
 
