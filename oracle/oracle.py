@@ -56,6 +56,17 @@ def build(force=False):
 _libs = {}
 
 
+def _limit_openmp():
+    """A GPU box shows every host CPU but the job owns a share of them (16 per GPU): an OpenMP team of 128
+    spin-waiting threads on 16 cores makes small parallel regions pathologically slow. Must run before libgomp loads."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(avail, 16))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def lib(serial=False):
     key = "serial" if serial else "omp"
     if key in _libs:
@@ -63,6 +74,7 @@ def lib(serial=False):
     so = os.path.join(_BUILD, "libwfpt_oracle_serial.so" if serial else "libwfpt_oracle.so")
     if not os.path.exists(so):
         build()
+    _limit_openmp()
     L = C.CDLL(so)
     vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
     L.orc_create.restype = vp

@@ -257,3 +257,42 @@ def test_batched_samples_equal_sequential(gpu, orc, batch):
         o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
         want = o.render(spp)
     o.close()
+
+
+@pytest.mark.parametrize("rng_mode", [0, 1])
+def test_per_material_stages_of_the_stage_api(gpu, orc, rng_mode):
+    """`shade_lambertian`, `shade_metal`, `shade_dielectric` (README.md:19's by-material kernels) run one after the
+    other over extend's material partition must equal the single `shade` stage: same extension rays in the same
+    slots, same image, counters[2] == hits."""
+    W = gpu
+    w, h = 400, 224
+    n = w * h
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, rng_mode=rng_mode)
+    pt = make_tracer(W, "shirley", w, h, rng_mode=rng_mode)
+    stages = [W.Kernel(name, pt) for name in ("shade_lambertian", "shade_metal", "shade_dielectric")]
+    pt.set_frame(W.GPUFrameBuffer.new(w, h, 9)); o.set_frame(9, 0)
+    pt.reset_image(); o.reset_image()
+    pt.set_counters([0, 0, n]); o.set_counters([0, 0, n])
+    pt.generate_ray_kernel.run((w // 8, h // 8)); o.generate_rays(w // 8, h // 8, False)
+    ext = W.workgroup_size_64(n)
+    for wavefront in range(3):
+        pt.extend_kernel.run(ext); o.extend(*ext)
+        c = o.counters()
+        hits, misses = int(c[1]), int(c[0])
+        c[2] = 0
+        pt.set_counters(c); o.set_counters(c)
+        sh = W.workgroup_size_64(hits)
+        emitted = []
+        for k in stages:  # any order gives the same result; each adds the rays it emits to counters[2]
+            k.run(sh)
+            emitted.append(int(pt.read_counters()[2]))
+        o.shade(*sh)
+        assert emitted[-1] == hits and emitted[0] > emitted[1] - emitted[0] > 0  # mostly lambertian, some metal
+        assert_bit_equal(pt.extension_rays(hits), o.extension_rays(hits).view(W.RAY), f"extension rays {wavefront}")
+        assert_bit_equal(pt.image(), o.image(), f"image {wavefront}")
+        ms = W.workgroup_size_64(misses)
+        pt.miss_kernel.run(ms); o.miss(*ms)
+        pt.swap_ray_queues(); o.swap_ray_queues()
+        ext = W.workgroup_size_64(hits)
+        pt.set_counters([0, 0, hits, 0]); o.set_counters([0, 0, hits, 0])
+    pt.close(); o.close()

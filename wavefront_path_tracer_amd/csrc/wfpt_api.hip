@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,8 @@ struct wfpt_ctx {
     float *hit_t = nullptr;
     uint32_t *hit_prim = nullptr, *hit_ridx = nullptr, *miss_ridx = nullptr;
     uint32_t *chunk_hits = nullptr, *chunk_miss = nullptr, *chunk_hit_base = nullptr, *chunk_miss_base = nullptr;
+    uint16_t *mat_list = nullptr; // [3][batch][capacity] per-material hit lists
+    uint32_t *chunk_mat = nullptr; // [3][batch][segments]
     float *image = nullptr, *accumulated = nullptr;
     Control *ctl = nullptr;
     CameraDev *camera = nullptr;
@@ -64,8 +67,7 @@ struct wfpt_ctx {
     uint32_t progress_frame = 0, accumulated_samples = 0;
     bool dev_frame_valid = false;
 
-    hipGraph_t graph[2] = {nullptr, nullptr};       // [0]: one sample, [1]: a full batch
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    std::map<uint32_t, std::pair<hipGraph_t, hipGraphExec_t>> graphs; // captured chain, keyed by samples per launch
 
     StageTimer timers[WFPT_STAGE_COUNT];
     std::vector<hipEvent_t> sample_events; // for wfpt_render_sample_timed
@@ -143,10 +145,11 @@ int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint
 }
 
 void destroy_graph(wfpt_ctx *c) {
-    for (int k = 0; k < 2; ++k) {
-        if (c->graph_exec[k]) { (void)hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; }
-        if (c->graph[k]) { (void)hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; }
+    for (auto &kv : c->graphs) {
+        if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+        if (kv.second.first) (void)hipGraphDestroy(kv.second.first);
     }
+    c->graphs.clear();
 }
 
 Batch batch_of(const wfpt_ctx *c, uint32_t n) {
@@ -183,9 +186,14 @@ GenerateArgs generate_args(wfpt_ctx *c, uint32_t gx, uint32_t gy, bool fused, ui
     a.tile = c->tile;
     return a;
 }
-ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit, uint32_t nb = 1) {
+ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit, uint32_t nb = 1, bool partition = true) {
     ExtendArgs a{};
     a.batch = batch_of(c, nb);
+    a.partition = partition ? 1u : 0u;
+    a.mat_list = c->mat_list;
+    a.chunk_mat = c->chunk_mat;
+    a.mat_list_mstride = static_cast<size_t>(c->batch_max) * c->capacity;
+    a.chunk_mat_mstride = static_cast<size_t>(c->batch_max) * c->n_chunks_max;
     a.q = c->q[qi];
     a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
     a.miss_ridx = c->miss_ridx;
@@ -215,6 +223,11 @@ ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit
                      bool count_out, uint32_t nb = 1) {
     ShadeArgs a{};
     a.batch = batch_of(c, nb);
+    a.split = (material != 0xffffffffu || (c->p.flags & WFPT_FLAG_SPLIT_SHADE)) ? 1u : 0u;
+    a.mat_list = c->mat_list;
+    a.chunk_mat = c->chunk_mat;
+    a.mat_list_mstride = static_cast<size_t>(c->batch_max) * c->capacity;
+    a.chunk_mat_mstride = static_cast<size_t>(c->batch_max) * c->n_chunks_max;
     a.q = c->q[qi];
     a.ext = c->q[qi ^ 1];
     a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
@@ -288,16 +301,15 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
         const int qi = static_cast<int>(b & 1u);
         WFPT_HIP(c, timed(WFPT_STAGE_EXTEND, [&] {
-                     return launch_extend(extend_args(c, qi, &c->ctl->n_in, c->capacity, nb), extend_grid(c, nb), c->stream);
+                     return launch_extend(extend_args(c, qi, &c->ctl->n_in, c->capacity, nb, split), extend_grid(c, nb), c->stream);
                  }));
         WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
                           [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb), c->stream); }));
-        if (split) {
-            for (uint32_t m = 0; m < 3; ++m)
-                WFPT_HIP(c, timed(WFPT_STAGE_SHADE_LAMBERTIAN + static_cast<int>(m), [&] {
-                             return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, m, false, nb),
-                                                 consumer_grid(c, nb), c->stream);
-                         }));
+        if (split) { // one launch, blockIdx.z = material class (README.md:19's by-material shade kernels)
+            WFPT_HIP(c, timed(WFPT_STAGE_SHADE_LAMBERTIAN, [&] {
+                         return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb),
+                                             consumer_grid(c, nb), c->stream);
+                     }));
         } else {
             WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] {
                          return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb),
@@ -323,23 +335,26 @@ int ensure_device_frame(wfpt_ctx *c) {
     return WFPT_OK;
 }
 
-// Renders `nb` samples (frames progress_frame+1 ...) with one pass of the chain; nb is 1 or batch_max.
+// Renders `nb` samples (frames progress_frame+1 ...) with one pass of the chain; 1 <= nb <= batch_max.
 int render_batch(wfpt_ctx *c, uint32_t nb) {
     WFPT_HIP(c, hipSetDevice(c->device));
     if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
     if (c->p.flags & WFPT_FLAG_NO_GRAPH) {
         if (int r = enqueue_batch(c, nullptr, nb); r != WFPT_OK) return r;
     } else {
-        const int slot = nb == 1 ? 0 : 1;
-        if (!c->graph_exec[slot]) {
+        auto it = c->graphs.find(nb);
+        if (it == c->graphs.end()) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
             WFPT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             const int r = enqueue_batch(c, nullptr, nb);
-            const hipError_t e = hipStreamEndCapture(c->stream, &c->graph[slot]);
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
             if (r != WFPT_OK) return r;
             if (e != hipSuccess) return hip_fail(c, e, "hipStreamEndCapture");
-            WFPT_HIP(c, hipGraphInstantiate(&c->graph_exec[slot], c->graph[slot], nullptr, nullptr, 0));
+            WFPT_HIP(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            it = c->graphs.emplace(nb, std::make_pair(g, ge)).first;
         }
-        WFPT_HIP(c, hipGraphLaunch(c->graph_exec[slot], c->stream));
+        WFPT_HIP(c, hipGraphLaunch(it->second.second, c->stream));
     }
     c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
     c->progress_frame += nb;      // the device advanced ctl->frame.frame itself
@@ -349,12 +364,11 @@ int render_batch(wfpt_ctx *c, uint32_t nb) {
 }
 
 int render_many(wfpt_ctx *c, uint32_t n_samples) {
-    while (n_samples >= c->batch_max && c->batch_max > 1) {
-        if (int r = render_batch(c, c->batch_max); r != WFPT_OK) return r;
-        n_samples -= c->batch_max;
+    while (n_samples > 0) { // full batches, then one smaller batch for the remainder
+        const uint32_t nb = std::min(n_samples, c->batch_max);
+        if (int r = render_batch(c, nb); r != WFPT_OK) return r;
+        n_samples -= nb;
     }
-    for (; n_samples > 0; --n_samples)
-        if (int r = render_batch(c, 1); r != WFPT_OK) return r;
     return WFPT_OK;
 }
 
@@ -520,6 +534,9 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(hipMemsetAsync(c->chunk_miss, 0, sizeof(uint32_t) * n_counts, c->stream));
     CREATE_HIP(hipMemsetAsync(c->chunk_hit_base, 0, sizeof(uint32_t) * n_counts, c->stream));
     CREATE_HIP(hipMemsetAsync(c->chunk_miss_base, 0, sizeof(uint32_t) * n_counts, c->stream));
+    CREATE_HIP(dmalloc(&c->mat_list, 3 * nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->chunk_mat, 3 * n_counts));
+    CREATE_HIP(hipMemsetAsync(c->chunk_mat, 0, sizeof(uint32_t) * 3 * n_counts, c->stream));
     c->image_floats = (3 * static_cast<size_t>(c->pixel_capacity) + 7) / 4 * 4; // slices stay 16-byte aligned
     CREATE_HIP(dmalloc(&c->image, nb * c->image_floats));
     CREATE_HIP(dmalloc(&c->accumulated, c->image_floats));
@@ -632,7 +649,8 @@ void wfpt_destroy(wfpt_ctx *c) {
     }
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
     void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_t, c->hit_prim, c->hit_ridx, c->miss_ridx, c->chunk_hits,
-                    c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->image, c->accumulated, c->ctl, c->camera,
+                    c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
+                    c->camera,
                     c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,
                     c->d_materials};
     for (void *b : bufs)
@@ -796,7 +814,7 @@ int wfpt_render_timed(wfpt_ctx *c, uint32_t n_samples, float *stage_ms, uint32_t
     if (!c || !stage_ms) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_timed: null argument");
     WFPT_HIP(c, hipSetDevice(c->device));
     while (n_samples > 0) {
-        const uint32_t nb = (n_samples >= c->batch_max) ? c->batch_max : 1u; // same batching as wfpt_render
+        const uint32_t nb = std::min(n_samples, c->batch_max); // same batching as wfpt_render
         if (int r = ensure_device_frame(c); r != WFPT_OK) return r;
         std::vector<EventRec> ev;
         if (int r = enqueue_batch(c, &ev, nb); r != WFPT_OK) return r;

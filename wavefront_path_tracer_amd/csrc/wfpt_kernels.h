@@ -115,6 +115,13 @@ struct ExtendArgs {
     const uint32_t *n_in; // rays to trace = min(*n_in, limit)
     uint32_t limit;
     uint32_t has_inactive; // ray queue may hold WFPT_INACTIVE_PIXEL padding rays
+    // per-material partition of each segment's hits (README.md:19 "split shade into by-material shade kernels"):
+    // list m of segment c holds, ascending, the in-segment ranks of its hits with material_type m
+    uint32_t partition;
+    uint16_t *mat_list;      // [3][batch][capacity]
+    uint32_t *chunk_mat;     // [3][batch][segments]
+    size_t mat_list_mstride; // elements between materials
+    size_t chunk_mat_mstride;
     SceneDev scene;
 };
 
@@ -141,7 +148,11 @@ struct ShadeArgs {
     uint32_t limit;
     uint32_t gx;            // stage API: the host's dispatch x extent; 0: use ctl->shade_gx
     uint32_t rng_mode;
-    uint32_t material;      // 0xffffffff: all; 0/1/2: only that material_type (per-material split)
+    uint32_t material;      // split != 0: 0/1/2 = walk only that material's lists, 0xffffffff = blockIdx.z picks
+    uint32_t split;         // walk the per-material lists instead of the whole hit queue
+    const uint16_t *mat_list;
+    const uint32_t *chunk_mat;
+    size_t mat_list_mstride, chunk_mat_mstride;
     uint32_t count_out;     // stage API: counters[2] += rays emitted (sh:155)
     uint32_t image_width;   // for the tile mapping
     SceneDev scene;

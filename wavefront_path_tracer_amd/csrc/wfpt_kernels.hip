@@ -158,12 +158,12 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
     return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
 }
 
-// Keeps all four components of an LDS float4 live so the load stays one ds_read_b128 (hipcc otherwise
-// narrows it to ds_read_b96 + ds_read_b32, which costs 2.5x the LDS cycles).
-__device__ __forceinline__ float4 lds_load4(const float4 *p) {
-    float4 v = *p;
-    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-    return v;
+// Marks all four components of loaded float4s as used, so each load stays one ds_read_b128 (hipcc otherwise
+// narrows a load whose .w is consumed elsewhere to ds_read_b96 + ds_read_b32: 2.5x the LDS cycles). Input-only
+// and placed after ALL loads of a step, so the loads issue back to back and are waited for once.
+__device__ __forceinline__ void keep4(const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y),
+                 "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
 }
 
 // trace_ray (ex:72-162) without a stack. The reference pushes the far child when t_far < nearest and
@@ -246,8 +246,8 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
 
 template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *prim_geom, const ParentT *pair_parent,
-                                          float ox, float oy, float oz, float dx, float dy, float dz, float &t_out,
-                                          uint32_t &prim_out) {
+                                          float ox, float oy, float oz, float dx, float dy, float dz, uint32_t max_steps,
+                                          float &t_out, uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
     const float a = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
     float nearest = 1e30f;
@@ -259,12 +259,16 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     tr.depth = 0;
     tr.trail = 0;
     bool alive = true;
+    // A traversal visits every node at most once, so `max_steps` (= node count) is never reached on a valid
+    // tree; it only guarantees that every wave terminates if the node data is corrupt.
+    uint32_t budget = max_steps;
     while (alive) {
         // ---- inner nodes (ex:105-138)
         while (alive && tr.prim_count == 0) {
+            if (budget-- == 0) { alive = false; break; }
             const float4 *pair = nodes + 2u * tr.left_first;
-            const float4 lmin = lds_load4(pair), lmax = lds_load4(pair + 1);
-            const float4 rmin = lds_load4(pair + 2), rmax = lds_load4(pair + 3);
+            const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
+            keep4(lmin, lmax, rmin, rmax);
             const float t_left = hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
             const float t_right = hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
             const bool swap = t_left > t_right; // strict: ties keep the left child first
@@ -281,6 +285,7 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
             }
         }
         // ---- leaf (ex:86-103)
+        if (alive && budget-- == 0) alive = false;
         if (alive) {
             for (uint32_t i = 0; i < tr.prim_count; ++i)
                 hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
     uint32_t *s_next = s_misc + 4 * kExtendWaves;
     uint32_t *s_rays = s_next + 2;
     uint32_t *s_first = s_rays + kMaxBatch;
+    uint32_t *s_mat = s_first + kMaxBatch + 1; // [2][3][kExtendWaves] per-material wave counts
 
     // Work items are (sample, segment) pairs, numbered sample-major.
     if (threadIdx.x == 0) {
@@ -364,16 +370,30 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
         bool hit = false;
         if (live) {
             if (LDS_SCENE)
-                hit = trace_ray<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, t, prim);
+                hit = trace_ray<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             else
                 hit = trace_ray<Trail, PRIM, uint32_t>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, ox, oy, oz, dx, dy,
-                                                        dz, t, prim);
+                                                        dz, a.scene.n_nodes, t, prim);
         }
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
         if (lane == 0) {
             s_misc[(buf * 2 + 0) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(hit_mask));
             s_misc[(buf * 2 + 1) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(miss_mask));
+        }
+        // material class of each hit (sphere.material_type, ex:199; `case 0u, default` of sh:102 folds > 2 into 0)
+        uint32_t mclass = 3u;
+        unsigned long long mat_mask[3] = {0, 0, 0};
+        if (a.partition) {
+            if (hit) {
+                mclass = PRIM == 0 ? a.scene.spheres[prim].material_type : __float_as_uint(a.scene.prim_geom[3u * prim + 1u].w);
+                if (mclass > 2u) mclass = 0u;
+            }
+#pragma unroll
+            for (uint32_t m = 0; m < 3; ++m) {
+                mat_mask[m] = __ballot(mclass == m);
+                if (lane == 0) s_mat[(buf * 3 + m) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(mat_mask[m]));
+            }
         }
         __syncthreads();
         uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
@@ -396,6 +416,22 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
         if (threadIdx.x == 0) {
             a.chunk_hits[co + chunk] = hit_total;
             a.chunk_miss[co + chunk] = miss_total;
+        }
+        if (a.partition) {
+#pragma unroll
+            for (uint32_t m = 0; m < 3; ++m) {
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < kExtendWaves; ++w) {
+                    const uint32_t cnt = s_mat[(buf * 3 + m) * kExtendWaves + w];
+                    before += (w < wave) ? cnt : 0u;
+                    total += cnt;
+                }
+                if (mclass == m) // entry = the hit's rank within the segment's hit queue; lists stay ascending
+                    a.mat_list[m * a.mat_list_mstride + seg + before + mbcnt(mat_mask[m])] =
+                        static_cast<uint16_t>(hit_before + mbcnt(hit_mask));
+                if (threadIdx.x == 0) a.chunk_mat[m * a.chunk_mat_mstride + co + chunk] = total;
+            }
         }
         item = s_next[buf];
         iter += 1;
@@ -538,15 +574,26 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
     const uint32_t n_hits = umin(a.n_hits[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit); // sh:66
     const uint32_t n_chunks = (a.ctl->seg_n + kChunk - 1) / kChunk;
     const uint32_t gx = a.gx ? a.gx : a.ctl->shade_gx;
-    const bool filtered = a.material != 0xffffffffu;
-    if (a.count_out && !filtered && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->counters[2] += n_hits; // sh:155
+    // split: this workgroup shades one material class, walking that class's per-segment lists (lanes stay
+    // packed and every lane takes the same branch of the material switch)
+    const bool split = a.split != 0;
+    const uint32_t mclass = a.material != 0xffffffffu ? a.material : blockIdx.z;
+    const uint16_t *mat_list = a.mat_list + mclass * a.mat_list_mstride + sample * a.batch.queue_stride;
+    const uint32_t *chunk_mat = a.chunk_mat + mclass * a.chunk_mat_mstride + sample * a.batch.chunk_stride;
+    if (a.count_out && !split && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->counters[2] += n_hits; // sh:155
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint32_t count = a.chunk_hits[chunk];
+        const uint32_t count = split ? chunk_mat[chunk] : a.chunk_hits[chunk];
         const uint32_t base = a.chunk_hit_base[chunk];
         if (base >= n_hits) break; // bases ascend with the segment index
-        for (uint32_t r = threadIdx.x; r < count; r += kConsumerThreads) {
+        for (uint32_t r0 = threadIdx.x; r0 < count; r0 += kConsumerThreads) {
+            const uint32_t r = split ? mat_list[chunk * kChunk + r0] : r0; // rank within the segment's hit queue
             const uint32_t h = base + r; // the reference's shade thread index
             if (h >= n_hits) break;
+            if (split && a.count_out) { // per-material stage of the stage API: counters[2] += rays this stage emits
+                const unsigned long long m = __ballot(true);
+                if (lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1))
+                    atomicAdd(&a.ctl->counters[2], static_cast<uint32_t>(__popcll(m)));
+            }
             const uint32_t slot = chunk * kChunk + r;
             const float t = a.hq.t[slot];
             const uint32_t prim = a.hq.prim[slot];
@@ -566,13 +613,6 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
                 mat_idx = tri.material_idx;
                 mat_type = tri.material_type;
             }
-            const bool mine = !filtered || a.material == (mat_type > 2u ? 0u : mat_type);
-            if (filtered && a.count_out) { // per-material stage: count only the rays this stage emits
-                const unsigned long long m = __ballot(mine);
-                if (m && lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1))
-                    atomicAdd(&a.ctl->counters[2], static_cast<uint32_t>(__popcll(m)));
-            }
-            if (!mine) continue;
             const float ox = a.q.ox[ridx], oy = a.q.oy[ridx], oz = a.q.oz[ridx];
             const float dx = a.q.dx[ridx], dy = a.q.dy[ridx], dz = a.q.dz[ridx];
             const uint32_t pixel_idx = a.q.pixel[ridx];
@@ -791,7 +831,7 @@ __global__ void selftest_math_kernel(int op, const float *a, const float *b, flo
 // launchers
 // ================================================================================================
 uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene) {
-    const uint32_t misc = 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u) + 16u;
+    const uint32_t misc = 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u + 6u * kExtendWaves) + 16u;
     if (!lds_scene) return misc;
     const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
     return 32u * n_nodes + 16u * (prim_kind == 0 ? 1u : 3u) * n_prims + 16u * parent_words + misc;
@@ -842,7 +882,8 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s) {
 
 hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(shade_kernel, dim3(grid, a.batch.n), dim3(kConsumerThreads), 0, s, a);
+    hipLaunchKernelGGL(shade_kernel, dim3(grid, a.batch.n, (a.split && a.material == 0xffffffffu) ? 3u : 1u), dim3(kConsumerThreads), 0,
+                       s, a);
     return hipGetLastError();
 }
 
