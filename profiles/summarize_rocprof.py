@@ -44,12 +44,15 @@ def pmc(path):
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     n_pixels = int(sys.argv[3]) if len(sys.argv) > 3 else 1920 * 1080
+    # samples per accumulate launch, in launch order (an accumulate launch of b samples reads (b + 1) * 12 B/pixel).
+    # Default = what `bench.py --steps 64 --warmup 4` does: warm-up 4, prime 16, 4 x 16 timed, 4 x 16 timed again.
+    acc_batches = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4] + [16] * 9
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(here, f"{tag}_kernel_stats.csv"))
     out = {}
-    for d in ("prof_fetch", "prof_write", "prof_sq"):
+    for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
         for p in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
             for k, counters in pmc(p).items():
                 for c, v in counters.items():
@@ -60,12 +63,15 @@ def main():
         fetch_kib, write_kib = ext["FETCH_SIZE"]["mean"], ext["WRITE_SIZE"]["mean"]
         cal = None
         if "FETCH_SIZE" in acc:
-            cal = (24.0 * n_pixels) / (acc["FETCH_SIZE"]["mean"] * 1024.0)  # true read bytes / reported
+            true_read = sum((b + 1) * 12.0 * n_pixels for b in acc_batches) / len(acc_batches)
+            cal = true_read / (acc["FETCH_SIZE"]["mean"] * 1024.0)  # true read bytes / reported
         summary = {
             "kernel": "extend_kernel", "launches": ext["FETCH_SIZE"]["launches"],
             "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
             "fetch_calibration_on_accumulate": cal,
             "accumulate_WRITE_SIZE_KiB_mean": acc.get("WRITE_SIZE", {}).get("mean"),
+            "note": "means over every extend launch of `python3 bench.py --steps 64 --warmup 4 --no-cpu-baseline` "
+                    "(16 samples in flight per launch); FETCH_SIZE doubled per the gfx950 correction (calibrated on accumulate)",
             "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024.0,
             "hbm_bytes_per_launch": ((cal or 1.0) * fetch_kib + write_kib) * 1024.0,
         }

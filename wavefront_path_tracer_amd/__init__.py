@@ -95,7 +95,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("WFPT_LIB", _build.LIB_PATH)  # WFPT_LIB: tuning builds made with WFPT_EXTRA_FLAGS / WFPT_LIB_OUT
     if not os.path.exists(path):
         raise WfptError(-5, f"{path} is missing: run wavefront_path_tracer_amd.build() "
                             "(python -m wavefront_path_tracer_amd._build); there is no CPU fallback")

@@ -38,7 +38,9 @@ def build(force=False, verbose=False):
     """Compile every HIP source into wavefront_path_tracer_amd/libwfpt.so; returns the path."""
     if not force and not stale():
         return LIB_PATH
-    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH]
+    out = os.environ.get("WFPT_LIB_OUT", LIB_PATH)  # tuning builds: WFPT_EXTRA_FLAGS="-D..." WFPT_LIB_OUT=...
+    cmd = [hipcc()] + FLAGS + os.environ.get("WFPT_EXTRA_FLAGS", "").split()
+    cmd += ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
@@ -47,7 +49,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + res.stdout)
     if verbose and res.stdout.strip():
         print(res.stdout)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
