@@ -6,6 +6,7 @@
 #include "wfpt_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -46,7 +47,9 @@ struct wfpt_ctx {
     RayQueue q[2]{};
     int cur = 0; // which queue is "ray_buffer"; the other one is "extension_ray_buffer"
     float *hit_t = nullptr;
-    uint32_t *hit_prim = nullptr, *hit_ridx = nullptr, *miss_ridx = nullptr;
+    uint32_t *hit_prim = nullptr, *hit_ridx = nullptr, *miss_ridx = nullptr, *miss_pixel = nullptr;
+    float *miss_dy = nullptr;
+    float4 *d_shade_rec = nullptr;
     uint32_t *chunk_hits = nullptr, *chunk_miss = nullptr, *chunk_hit_base = nullptr, *chunk_miss_base = nullptr;
     uint16_t *mat_list = nullptr; // [3][batch][capacity] per-material hit lists
     uint32_t *chunk_mat = nullptr; // [3][batch][segments]
@@ -197,6 +200,8 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.q = c->q[qi];
     a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
     a.miss_ridx = c->miss_ridx;
+    a.miss_dy = c->miss_dy;
+    a.miss_pixel = c->miss_pixel;
     a.chunk_hits = c->chunk_hits;
     a.chunk_miss = c->chunk_miss;
     a.ctl = c->ctl;
@@ -250,6 +255,8 @@ MissArgs miss_args(wfpt_ctx *c, int qi, const uint32_t *n_miss, uint32_t limit, 
     a.batch = batch_of(c, nb);
     a.q = c->q[qi];
     a.miss_ridx = c->miss_ridx;
+    a.miss_dy = c->miss_dy;
+    a.miss_pixel = c->miss_pixel;
     a.chunk_miss = c->chunk_miss; a.chunk_miss_base = c->chunk_miss_base;
     a.image = c->image;
     a.ctl = c->ctl;
@@ -525,6 +532,8 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(dmalloc(&c->hit_prim, nb * c->capacity));
     CREATE_HIP(dmalloc(&c->hit_ridx, nb * c->capacity));
     CREATE_HIP(dmalloc(&c->miss_ridx, nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->miss_dy, nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->miss_pixel, nb * c->capacity));
     const size_t n_counts = nb * c->n_chunks_max;
     CREATE_HIP(dmalloc(&c->chunk_hits, n_counts));
     CREATE_HIP(dmalloc(&c->chunk_miss, n_counts));
@@ -568,6 +577,31 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         CREATE_HIP(dmalloc(&c->d_triangles, n_spheres));
         CREATE_HIP(hipMemcpy(c->d_triangles, triangles, sizeof(wfpt_triangle) * n_spheres, hipMemcpyHostToDevice));
         c->scene.prim_geom = reinterpret_cast<const float4 *>(c->d_triangles); // 3 x float4 per triangle
+    }
+    // per-primitive shade records (sphere / triangle fields merged with the material they point at)
+    {
+        std::vector<ShadeRec> recs(n_spheres);
+        for (uint32_t i = 0; i < n_spheres; ++i) {
+            ShadeRec &r = recs[i];
+            const wfpt_material &m = materials[spheres ? spheres[i].material_idx : triangles[i].material_idx];
+            if (spheres) {
+                r.v[0] = spheres[i].center[0]; r.v[1] = spheres[i].center[1]; r.v[2] = spheres[i].center[2];
+            } else { // normalize(cross(e1, e2)): fixed operation order, true divisions, no contraction (-ffp-contract=off)
+                const float *e1 = triangles[i].e1, *e2 = triangles[i].e2;
+                const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                const float len = std::sqrt((nx * nx + ny * ny) + nz * nz);
+                r.v[0] = nx / len; r.v[1] = ny / len; r.v[2] = nz / len;
+            }
+            r.fuzz = m.fuzz;
+            r.albedo[0] = m.albedo[0]; r.albedo[1] = m.albedo[1]; r.albedo[2] = m.albedo[2];
+            r.refract_index = m.refract_index;
+            r.mat_type = c->h_prim_mat_type[i]; // sphere.material_type, which extend copies into the payload (ex:199)
+            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+        }
+        static_assert(sizeof(ShadeRec) == 48, "ShadeRec is read as three float4");
+        CREATE_HIP(dmalloc(&c->d_shade_rec, 3 * static_cast<size_t>(n_spheres)));
+        CREATE_HIP(hipMemcpy(c->d_shade_rec, recs.data(), sizeof(ShadeRec) * n_spheres, hipMemcpyHostToDevice));
+        c->scene.shade_rec = c->d_shade_rec;
     }
     // LDS variant when nodes + primitives + parents fit comfortably (>= 2 workgroups per CU); otherwise the
     // scene stays in HBM / Infinity Cache and extend reads it through L2.
@@ -648,7 +682,8 @@ void wfpt_destroy(wfpt_ctx *c) {
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
-    void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_t, c->hit_prim, c->hit_ridx, c->miss_ridx, c->chunk_hits,
+    void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_t, c->hit_prim, c->hit_ridx, c->miss_ridx, c->miss_dy, c->miss_pixel,
+                    c->d_shade_rec, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera,
                     c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,

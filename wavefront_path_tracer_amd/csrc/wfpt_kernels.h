@@ -12,7 +12,10 @@ namespace wfpt {
 // segment at a time and leaves that segment's hits and misses compacted (stable) at the front of the
 // matching segment of the hit / miss queues; a one-workgroup scan then turns the per-segment counts
 // into global queue positions. See DESIGN.md "Queues".
-constexpr int kChunk = 512;
+#ifndef WFPT_CHUNK
+#define WFPT_CHUNK 512 // rays per queue segment = threads of an extend workgroup (tuning builds: 256 / 512 / 1024)
+#endif
+constexpr int kChunk = WFPT_CHUNK;
 constexpr int kExtendThreads = kChunk;
 constexpr int kExtendWaves = kExtendThreads / 64;
 constexpr int kConsumerThreads = 256;
@@ -54,6 +57,19 @@ struct Control {
     unsigned long long totals[4]; // rays traced, hits, misses, samples
 };
 
+// What shade needs to know about a primitive, merged into one 48-byte record (three float4) so that one
+// gather replaces the reference's dependent sphere -> material look-ups (shade.wgsl:80-84):
+// v = sphere centre, or for a triangle its unit normal normalize(cross(e1, e2)) (computed once on the host
+// with the same operation order the oracle uses per hit).
+struct ShadeRec {
+    float v[3];
+    float fuzz;
+    float albedo[3];
+    float refract_index;
+    uint32_t mat_type;
+    uint32_t _pad[3];
+};
+
 struct SceneDev {
     const wfpt_bvh_node *nodes;   // reference layout, 32 B
     const float4 *prim_geom;      // spheres: (cx, cy, cz, r), 16 B each; triangles: the wfpt_triangle array, 3 x 16 B each
@@ -62,6 +78,7 @@ struct SceneDev {
     const wfpt_sphere *spheres;   // reference layout (shade reads material_idx / material_type)
     const wfpt_triangle *triangles;
     const wfpt_material *materials;
+    const float4 *shade_rec;      // ShadeRec per primitive, as 3 x float4
     uint32_t n_nodes, n_spheres, n_materials; // n_spheres = primitive count
     uint32_t prim_kind;           // 0 spheres (the reference), 1 triangles (build extension)
     uint32_t lds_scene;           // 1: nodes + primitives + parents are staged in LDS by extend
@@ -110,6 +127,8 @@ struct ExtendArgs {
     RayQueue q;
     HitQueue hq;
     uint32_t *miss_ridx;
+    float *miss_dy;       // miss queue payload: direction.y and pixel of the missing ray, so miss_kernel needs no gather
+    uint32_t *miss_pixel;
     uint32_t *chunk_hits, *chunk_miss;
     Control *ctl;
     const uint32_t *n_in; // rays to trace = min(*n_in, limit)
@@ -163,6 +182,8 @@ struct MissArgs {
     Batch batch;
     RayQueue q;
     const uint32_t *miss_ridx;
+    const float *miss_dy;
+    const uint32_t *miss_pixel;
     const uint32_t *chunk_miss, *chunk_miss_base;
     float *image;
     const Control *ctl;

@@ -412,7 +412,12 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
             a.hq.prim[slot] = prim;
             a.hq.ridx[slot] = idx;
         }
-        if (miss) a.miss_ridx[seg + miss_before + mbcnt(miss_mask)] = idx; // ex:61
+        if (miss) { // ex:61, plus what miss_kernel reads of the ray (mk:29-32)
+            const size_t slot = seg + miss_before + mbcnt(miss_mask);
+            a.miss_ridx[slot] = idx;
+            a.miss_dy[slot] = dy;
+            a.miss_pixel[slot] = q.pixel[idx];
+        }
         if (threadIdx.x == 0) {
             a.chunk_hits[co + chunk] = hit_total;
             a.chunk_miss[co + chunk] = miss_total;
@@ -585,45 +590,45 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
         const uint32_t count = split ? chunk_mat[chunk] : a.chunk_hits[chunk];
         const uint32_t base = a.chunk_hit_base[chunk];
         if (base >= n_hits) break; // bases ascend with the segment index
-        for (uint32_t r0 = threadIdx.x; r0 < count; r0 += kConsumerThreads) {
-            const uint32_t r = split ? mat_list[chunk * kChunk + r0] : r0; // rank within the segment's hit queue
+        // Software-pipelined walk: the queue entry of the NEXT iteration is loaded before this iteration's
+        // dependent gathers, so each hit costs two dependent memory levels instead of three.
+        uint32_t r0 = threadIdx.x;
+        uint32_t nr = 0, nprim = 0, nridx = 0;
+        float nt = 0.0f;
+        if (r0 < count) {
+            nr = split ? mat_list[chunk * kChunk + r0] : r0; // rank within the segment's hit queue
+            nt = a.hq.t[chunk * kChunk + nr];
+            nprim = a.hq.prim[chunk * kChunk + nr];
+            nridx = a.hq.ridx[chunk * kChunk + nr];
+        }
+        for (; r0 < count; r0 += kConsumerThreads) {
+            const uint32_t r = nr, prim = nprim, ridx = nridx;
+            const float t = nt;
             const uint32_t h = base + r; // the reference's shade thread index
             if (h >= n_hits) break;
+            if (r0 + kConsumerThreads < count) {
+                nr = split ? mat_list[chunk * kChunk + r0 + kConsumerThreads] : r0 + kConsumerThreads;
+                nt = a.hq.t[chunk * kChunk + nr];
+                nprim = a.hq.prim[chunk * kChunk + nr];
+                nridx = a.hq.ridx[chunk * kChunk + nr];
+            }
             if (split && a.count_out) { // per-material stage of the stage API: counters[2] += rays this stage emits
                 const unsigned long long m = __ballot(true);
                 if (lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1))
                     atomicAdd(&a.ctl->counters[2], static_cast<uint32_t>(__popcll(m)));
             }
-            const uint32_t slot = chunk * kChunk + r;
-            const float t = a.hq.t[slot];
-            const uint32_t prim = a.hq.prim[slot];
-            const uint32_t ridx = a.hq.ridx[slot];
-            // primitive record: centre (sphere) or the two edges (triangle), material index and type
-            float c_x = 0.0f, c_y = 0.0f, c_z = 0.0f, e1x = 0.0f, e1y = 0.0f, e1z = 0.0f, e2x = 0.0f, e2y = 0.0f, e2z = 0.0f;
-            uint32_t mat_idx, mat_type; // mat_type == payload.mat_type (ex:199)
-            if (a.scene.prim_kind == 0) {
-                const wfpt_sphere sph = a.scene.spheres[prim];
-                c_x = sph.center[0]; c_y = sph.center[1]; c_z = sph.center[2];
-                mat_idx = sph.material_idx;
-                mat_type = sph.material_type;
-            } else {
-                const wfpt_triangle tri = a.scene.triangles[prim];
-                e1x = tri.e1[0]; e1y = tri.e1[1]; e1z = tri.e1[2];
-                e2x = tri.e2[0]; e2y = tri.e2[1]; e2z = tri.e2[2];
-                mat_idx = tri.material_idx;
-                mat_type = tri.material_type;
-            }
+            // one gather: primitive centre / normal, albedo, fuzz, refraction index, material type (== payload.mat_type, ex:199)
+            const float4 rec0 = a.scene.shade_rec[3u * prim], rec1 = a.scene.shade_rec[3u * prim + 1u],
+                         rec2 = a.scene.shade_rec[3u * prim + 2u];
+            const uint32_t mat_type = __float_as_uint(rec2.x);
+            struct { float albedo[3]; float fuzz, refract_index; } mat = {{rec1.x, rec1.y, rec1.z}, rec0.w, rec1.w};
             const float ox = a.q.ox[ridx], oy = a.q.oy[ridx], oz = a.q.oz[ridx];
             const float dx = a.q.dx[ridx], dy = a.q.dy[ridx], dz = a.q.dz[ridx];
             const uint32_t pixel_idx = a.q.pixel[ridx];
-            const wfpt_material mat = a.scene.materials[mat_idx];
-
-            // sh:84-87: throughput *= albedo, for every material type
+            // sh:84-87: throughput *= albedo, for every material type (load now, store after the scatter math)
             const uint32_t lp = local_pixel(pixel_idx, a.image_width, a.tile);
             float *px = a.image + 3u * static_cast<size_t>(lp);
-            px[0] = px[0] * mat.albedo[0];
-            px[1] = px[1] * mat.albedo[1];
-            px[2] = px[2] * mat.albedo[2];
+            const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
 
             // sh:71-73: RNG keyed by the dispatch's global_invocation_id (or by the pixel)
             uint32_t id_x, id_y;
@@ -642,9 +647,8 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             // sh:91-93
             const float p_x = ox + t * dx, p_y = oy + t * dy, p_z = oz + t * dz;
             // spheres: always-outward normal (sh:93); triangles: normalize(cross(e1, e2)), never flipped
-            const float3_ nrm = a.scene.prim_kind == 0
-                                    ? normalize3({p_x - c_x, p_y - c_y, p_z - c_z})
-                                    : normalize3({e1y * e2z - e1z * e2y, e1z * e2x - e1x * e2z, e1x * e2y - e1y * e2x});
+            const float3_ nrm = a.scene.prim_kind == 0 ? normalize3({p_x - rec0.x, p_y - rec0.y, p_z - rec0.z})
+                                                       : float3_{rec0.x, rec0.y, rec0.z};
             const float3_ rdir = {dx, dy, dz};
             float3_ ext;
             if (mat_type == 1u) { // sh:110-114 metal
@@ -686,6 +690,9 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             a.ext.ox[h] = p_x; a.ext.oy[h] = p_y; a.ext.oz[h] = p_z;
             a.ext.dx[h] = ext.x; a.ext.dy[h] = ext.y; a.ext.dz[h] = ext.z;
             a.ext.pixel[h] = pixel_idx;
+            px[0] = thr_r * mat.albedo[0];
+            px[1] = thr_g * mat.albedo[1];
+            px[2] = thr_b * mat.albedo[2];
         }
     }
 }
@@ -697,7 +704,8 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
     const uint32_t sample = blockIdx.y;
     a.ctl += sample;
     a.q = slice(a.q, sample * a.batch.ray_stride);
-    a.miss_ridx += sample * a.batch.queue_stride;
+    a.miss_dy += sample * a.batch.queue_stride;
+    a.miss_pixel += sample * a.batch.queue_stride;
     a.chunk_miss += sample * a.batch.chunk_stride;
     a.chunk_miss_base += sample * a.batch.chunk_stride;
     a.image += sample * a.batch.image_stride;
@@ -709,9 +717,8 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
         if (base >= n_miss) break;
         for (uint32_t r = threadIdx.x; r < count; r += kConsumerThreads) {
             if (base + r >= n_miss) break;
-            const uint32_t ridx = a.miss_ridx[chunk * kChunk + r];
-            const float dy = a.q.dy[ridx];
-            const uint32_t pixel_idx = a.q.pixel[ridx];
+            const float dy = a.miss_dy[chunk * kChunk + r]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
+            const uint32_t pixel_idx = a.miss_pixel[chunk * kChunk + r];
             const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
             const float om = 1.0f - t;
             const float cr = om * 1.0f + t * 0.5f; // mk:33
