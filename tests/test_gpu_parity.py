@@ -296,3 +296,62 @@ def test_per_material_stages_of_the_stage_api(gpu, orc, rng_mode):
         ext = W.workgroup_size_64(hits)
         pt.set_counters([0, 0, hits, 0]); o.set_counters([0, 0, hits, 0])
     pt.close(); o.close()
+
+
+# ------------------------------------------------------------------ edge cases
+def _single_sphere_inputs(orc, w, h):
+    sp = np.zeros(1, orc.SPHERE)
+    sp["center"][0] = (0.0, 0.0, -1.0, 1.0)
+    sp["radius"] = 0.5
+    mt = np.zeros(1, orc.MATERIAL)
+    mt["albedo"][0] = (0.8, 0.3, 0.3, 1.0)
+    sp, nodes = orc.build_bvh(sp)  # the root is a leaf (extend.wgsl:84: its box is never tested)
+    cam, ip, vw = orc.camera((0.0, 0.0, 1.0), (0.0, 0.0, -1.0), 60.0, 0.0, 10.0, 0.1, 100.0, w, h)
+    return sp, mt, nodes, cam, ip, vw
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 8), (24, 16), (100, 64), (64, 100), (33, 17)])
+@pytest.mark.parametrize("rng_mode", [0, 1])
+def test_small_and_ragged_sizes(gpu, orc, w, h, rng_mode):
+    """8x8 is one workgroup (the reference's workgroup_size_64 panics for <= 64 threads; the build defines (1,1));
+    ragged sizes exercise the true-size rule in both dimensions."""
+    W = gpu
+    o = make_oracle(orc, inputs_for(orc, "simple", w, h), w, h, rng_mode=rng_mode, max_wavefronts=5, miss_floor=0)
+    pt = make_tracer(W, "simple", w, h, rng_mode=rng_mode, max_wavefronts=5, miss_floor=0)
+    for _ in range(3):
+        o.render_sample(); pt.render_sample()
+        assert np.array_equal(pt.bounce_table(), o.bounce_table())
+    assert_bit_equal(pt.accumulated(), o.accumulated(), f"{w}x{h}")
+    pt.close(); o.close()
+
+
+def test_single_sphere_root_leaf(gpu, orc):
+    W = gpu
+    w, h = 64, 48
+    inputs = _single_sphere_inputs(orc, w, h)
+    o = make_oracle(orc, inputs, w, h, max_wavefronts=4, miss_floor=0)
+    scene = W.Scene(inputs[0].view(W.SPHERE), inputs[1].view(W.MATERIAL))
+    cc = W.CameraController(W.Camera((0.0, 0.0, 1.0), (0.0, 0.0, -1.0)), 60.0, 0.0, 10.0, 0.1, 100.0)
+    pt = W.PathTracer(scene, W.RenderParameters(cc, (w, h)), max_wavefronts=4, miss_floor=0)
+    assert len(pt.bvh_tree.nodes) == 2 and pt.bvh_tree.nodes[0]["prim_count"] == 1
+    o.render(2); pt.render(2)
+    assert_bit_equal(pt.accumulated(), o.accumulated(), "single sphere")
+    t = pt.bounce_table()
+    assert t[0, 1] > 0 and t[0, 2] > 0  # some primary rays hit the sphere, some the sky
+    pt.close(); o.close()
+
+
+@pytest.mark.parametrize("max_wavefronts,miss_floor", [(1, 128), (3, 0), (50, 10 ** 9), (50, 128), (64, 1)])
+def test_loop_termination_policies(gpu, orc, max_wavefronts, miss_floor):
+    """path_tracer.rs:323,332: `wavefront < max` and `misses < miss_floor -> break` evaluated on the device.
+    miss_floor = 1e9 leaves after the first extend: nothing is shaded, every pixel accumulates its initial 1.0."""
+    W = gpu
+    w, h, spp = 120, 80, 2
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=max_wavefronts, miss_floor=miss_floor)
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=max_wavefronts, miss_floor=miss_floor)
+    o.render(spp); pt.render(spp)
+    assert np.array_equal(pt.bounce_table(), o.bounce_table())
+    assert_bit_equal(pt.accumulated(), o.accumulated(), f"max {max_wavefronts}, floor {miss_floor}")
+    if miss_floor == 10 ** 9:
+        assert (pt.accumulated() == spp).all() and len(pt.bounce_table()) == 1
+    pt.close(); o.close()

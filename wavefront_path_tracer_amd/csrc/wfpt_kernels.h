@@ -18,7 +18,10 @@ namespace wfpt {
 constexpr int kChunk = WFPT_CHUNK;
 constexpr int kExtendThreads = kChunk;
 constexpr int kExtendWaves = kExtendThreads / 64;
-constexpr int kConsumerThreads = 256;
+#ifndef WFPT_CONSUMER_THREADS
+#define WFPT_CONSUMER_THREADS 256
+#endif
+constexpr int kConsumerThreads = WFPT_CONSUMER_THREADS;
 constexpr int kScanThreads = 1024;
 constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
 constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64

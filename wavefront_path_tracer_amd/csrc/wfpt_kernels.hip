@@ -715,10 +715,21 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
         const uint32_t count = a.chunk_miss[chunk];
         const uint32_t base = a.chunk_miss_base[chunk];
         if (base >= n_miss) break;
+        // software-pipelined like shade: the next entry is loaded before this entry's image read-modify-write
+        float ndy = 0.0f;
+        uint32_t npix = 0;
+        if (threadIdx.x < count) {
+            ndy = a.miss_dy[chunk * kChunk + threadIdx.x]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
+            npix = a.miss_pixel[chunk * kChunk + threadIdx.x];
+        }
         for (uint32_t r = threadIdx.x; r < count; r += kConsumerThreads) {
             if (base + r >= n_miss) break;
-            const float dy = a.miss_dy[chunk * kChunk + r]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
-            const uint32_t pixel_idx = a.miss_pixel[chunk * kChunk + r];
+            const float dy = ndy;
+            const uint32_t pixel_idx = npix;
+            if (r + kConsumerThreads < count) {
+                ndy = a.miss_dy[chunk * kChunk + r + kConsumerThreads];
+                npix = a.miss_pixel[chunk * kChunk + r + kConsumerThreads];
+            }
             const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
             const float om = 1.0f - t;
             const float cr = om * 1.0f + t * 0.5f; // mk:33
