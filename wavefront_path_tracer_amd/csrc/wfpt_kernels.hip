@@ -177,18 +177,37 @@ __device__ __forceinline__ void keep4(const float4 &a, const float4 &b, const fl
 // done), then all leaf lanes test their spheres together. Each lane still performs exactly the
 // reference's sequence of operations; only the interleaving across lanes changes, which keeps more lanes
 // active per instruction than alternating leaf/inner work every iteration.
-template <typename Trail, typename ParentT>
+// STACK_DEPTH > 0 (HBM-resident scenes, where a parent-table step is an L2 round trip): the last STACK_DEPTH pushed
+// nodes are also kept in a per-lane LDS column, so a pop is one ds_read. The trail stays authoritative; pushes
+// beyond the column's depth are only counted (`lost`) and popped by the parent walk, which keeps LIFO order because
+// the lost entries are always the most recent ones.
+constexpr uint32_t kStackDepth = 16;
+
+template <typename Trail, typename ParentT, uint32_t STACK_DEPTH = 0>
 struct Traversal {
     uint32_t node, left_first, prim_count, depth;
     Trail trail;
+    uint32_t sp = 0, lost = 0;
+    uint32_t *stack = nullptr; // this lane's column: entry k at stack[k * kExtendThreads]
+
+    __device__ __forceinline__ void push(uint32_t far_node) {
+        if (STACK_DEPTH == 0) return;
+        if (sp < STACK_DEPTH) stack[(sp++) * kExtendThreads] = far_node;
+        else lost += 1;
+    }
 
     // LIFO pop: deepest pending level. Returns false when nothing is pending (ex:95-97, 125-127: break).
     __device__ __forceinline__ bool pop(const float4 *nodes, const ParentT *pair_parent) {
         if (trail == 0) return false;
         const uint32_t level = (sizeof(Trail) == 8) ? 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(trail)))
                                                     : 31u - static_cast<uint32_t>(__clz(static_cast<int>(trail)));
-        for (uint32_t k = depth; k > level; --k) node = pair_parent[node >> 1];
-        node ^= 1u;
+        if (STACK_DEPTH > 0 && lost == 0) {
+            node = stack[(--sp) * kExtendThreads];
+        } else {
+            for (uint32_t k = depth; k > level; --k) node = pair_parent[node >> 1];
+            node ^= 1u;
+            if (STACK_DEPTH > 0) lost -= 1;
+        }
         trail &= ~(static_cast<Trail>(1) << level);
         depth = level;
         left_first = __float_as_uint(nodes[2u * node].w);
@@ -244,15 +263,16 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
     }
 }
 
-template <typename Trail, int PRIM, typename ParentT>
+template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH>
 __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *prim_geom, const ParentT *pair_parent,
-                                          float ox, float oy, float oz, float dx, float dy, float dz, uint32_t max_steps,
-                                          float &t_out, uint32_t &prim_out) {
+                                          uint32_t *stack_column, float ox, float oy, float oz, float dx, float dy,
+                                          float dz, uint32_t max_steps, float &t_out, uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
     const float a = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
-    Traversal<Trail, ParentT> tr;
+    Traversal<Trail, ParentT, STACK_DEPTH> tr;
+    tr.stack = stack_column;
     tr.node = 0; // ex:84: the root's box is never tested
     tr.left_first = __float_as_uint(nodes[0].w);
     tr.prim_count = __float_as_uint(nodes[1].w);
@@ -279,7 +299,10 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
             } else { // ex:132-137: descend into the near child, remember the far one
                 tr.node = tr.left_first + (swap ? 1u : 0u);
                 tr.depth += 1;
-                if (t_far < nearest) tr.trail |= static_cast<Trail>(1) << tr.depth;
+                if (t_far < nearest) {
+                    tr.trail |= static_cast<Trail>(1) << tr.depth;
+                    tr.push(tr.left_first + (swap ? 0u : 1u));
+                }
                 tr.left_first = __float_as_uint(swap ? rmin.w : lmin.w);
                 tr.prim_count = __float_as_uint(swap ? rmax.w : lmax.w);
             }
@@ -319,6 +342,7 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
     uint32_t *s_rays = s_next + 2;
     uint32_t *s_first = s_rays + kMaxBatch;
     uint32_t *s_mat = s_first + kMaxBatch + 1; // [2][3][kExtendWaves] per-material wave counts
+    uint32_t *s_stack = s_mat + 6 * kExtendWaves; // HBM-resident scenes: [kStackDepth][kExtendThreads] node stack
 
     // Work items are (sample, segment) pairs, numbered sample-major.
     if (threadIdx.x == 0) {
@@ -370,10 +394,12 @@ __global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
         bool hit = false;
         if (live) {
             if (LDS_SCENE)
-                hit = trace_ray<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                hit = trace_ray<Trail, PRIM, uint16_t, 0>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
+                                                          prim);
             else
-                hit = trace_ray<Trail, PRIM, uint32_t>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, ox, oy, oz, dx, dy,
-                                                        dz, a.scene.n_nodes, t, prim);
+                hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
+                                                                     s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
+                                                                     a.scene.n_nodes, t, prim);
         }
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
@@ -850,7 +876,7 @@ __global__ void selftest_math_kernel(int op, const float *a, const float *b, flo
 // ================================================================================================
 uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene) {
     const uint32_t misc = 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u + 6u * kExtendWaves) + 16u;
-    if (!lds_scene) return misc;
+    if (!lds_scene) return misc + 4u * kStackDepth * kExtendThreads;
     const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
     return 32u * n_nodes + 16u * (prim_kind == 0 ? 1u : 3u) * n_prims + 16u * parent_words + misc;
 }
