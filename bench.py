@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="CPU-baseline sample: whole samples per pixel of the same workload until this much time is spent")
     ap.add_argument("--no-stage-times", action="store_true")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only -- ranks may share one GPU, "
@@ -74,13 +75,13 @@ def cpu_baseline(args, rng_mode):
         o.render_sample()
         spp += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or spp >= 4:
+        if el >= args.cpu_seconds or spp >= max(args.steps, 4):
             break
     rays = int(o.totals()[0])
     cores = O.lib().orc_num_threads()
     o.close()
     return {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{spp} of the workload's samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
+            "sample": f"{spp} of the workload's {args.steps} samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
                       f"{rays} rays, {el:.1f} s, OpenMP x{cores})"}
 
 
@@ -194,7 +195,9 @@ def main():
         launches += l
         rt = pt.totals() - r0
         ext_ms, ext_n = float(ms[W.STAGES["extend"]]), int(launches[W.STAGES["extend"]])
-        ext_bytes = 24.0 * float(rt[0]) + 12.0 * float(rt[1]) + 4.0 * float(rt[2])  # 24 B/ray in, 12 B/hit, 4 B/miss
+        # SURVEY 8(d)'s algorithmic figure: 24 B/ray in, 12 B/hit, 4 B/miss. (The kernel additionally hands miss_kernel
+        # (dir.y, pixel) through the miss queue: +12 B/miss, visible in the PMC traffic below.)
+        ext_bytes = 24.0 * float(rt[0]) + 12.0 * float(rt[1]) + 4.0 * float(rt[2])
         shade_ms = float(sum(ms[W.STAGES[k]] for k in ("shade", "shade_lambertian", "shade_metal", "shade_dielectric")))
         stage = {"ms": {k: round(float(ms[v]), 4) for k, v in W.STAGES.items() if launches[v]},
                  "launches": {k: int(launches[v]) for k, v in W.STAGES.items() if launches[v]},

@@ -45,8 +45,8 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     n_pixels = int(sys.argv[3]) if len(sys.argv) > 3 else 1920 * 1080
     # samples per accumulate launch, in launch order (an accumulate launch of b samples reads (b + 1) * 12 B/pixel).
-    # Default = what `bench.py --steps 64 --warmup 4` does: warm-up 4, prime 16, 4 x 16 timed, 4 x 16 timed again.
-    acc_batches = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4] + [16] * 9
+    # Default = what `bench.py --steps 64 --warmup 16` does: warm-up 16, prime 16, 4 x 16 timed, 4 x 16 timed again.
+    acc_batches = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [16] * 10
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
     if stats:
@@ -70,8 +70,9 @@ def main():
             "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
             "fetch_calibration_on_accumulate": cal,
             "accumulate_WRITE_SIZE_KiB_mean": acc.get("WRITE_SIZE", {}).get("mean"),
-            "note": "means over every extend launch of `python3 bench.py --steps 64 --warmup 4 --no-cpu-baseline` "
-                    "(16 samples in flight per launch); FETCH_SIZE doubled per the gfx950 correction (calibrated on accumulate)",
+            "note": "means over every extend launch of `python3 bench.py --steps 64 --warmup 16 --no-cpu-baseline` "
+                    "(every launch carries 16 samples); FETCH_SIZE x fetch_calibration (gfx950 reports half the read bytes; "
+                    "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE is exact",
             "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024.0,
             "hbm_bytes_per_launch": ((cal or 1.0) * fetch_kib + write_kib) * 1024.0,
         }
