@@ -168,7 +168,7 @@ __device__ __forceinline__ void keep4(const float4 &a, const float4 &b, const fl
 
 // trace_ray (ex:72-162) without a stack. The reference pushes the far child when t_far < nearest and
 // pops LIFO; pushes along one descent have strictly increasing depth, so "the stack" is exactly the set
-// of tree levels with a pending far sibling: one bit per level (`trail`). Siblings sit at (2k, 2k+1)
+// of tree levels with a pending far sibling: one bit per level (`trail`, kept as a shift register). Siblings sit at (2k, 2k+1)
 // (bvh.rs:160, 191-206), so the pending node at a level is (path node at that level) ^ 1, and the path
 // node is found by walking `pair_parent` up from the current node. Same visit order, same comparisons,
 // same results as the stack version, but no per-lane stack memory.
@@ -185,8 +185,8 @@ constexpr uint32_t kStackDepth = 16;
 
 template <typename Trail, typename ParentT, uint32_t STACK_DEPTH = 0>
 struct Traversal {
-    uint32_t node, left_first, prim_count, depth;
-    Trail trail;
+    uint32_t node, left_first, prim_count;
+    Trail trail; // shift register: bit i = "the far sibling is still pending" at the path node i levels above the current one
     uint32_t sp = 0, lost = 0;
     uint32_t *stack = nullptr; // this lane's column: entry k at stack[k * kExtendThreads]
 
@@ -199,17 +199,17 @@ struct Traversal {
     // LIFO pop: deepest pending level. Returns false when nothing is pending (ex:95-97, 125-127: break).
     __device__ __forceinline__ bool pop(const float4 *nodes, const ParentT *pair_parent) {
         if (trail == 0) return false;
-        const uint32_t level = (sizeof(Trail) == 8) ? 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(trail)))
-                                                    : 31u - static_cast<uint32_t>(__clz(static_cast<int>(trail)));
+        // levels to climb to the deepest pending sibling = trailing zeros
+        const uint32_t up = (sizeof(Trail) == 8) ? static_cast<uint32_t>(__ffsll(static_cast<long long>(trail)) - 1)
+                                                 : static_cast<uint32_t>(__ffs(static_cast<int>(trail)) - 1);
         if (STACK_DEPTH > 0 && lost == 0) {
             node = stack[(--sp) * kExtendThreads];
         } else {
-            for (uint32_t k = depth; k > level; --k) node = pair_parent[node >> 1];
+            for (uint32_t k = 0; k < up; ++k) node = pair_parent[node >> 1];
             node ^= 1u;
             if (STACK_DEPTH > 0) lost -= 1;
         }
-        trail &= ~(static_cast<Trail>(1) << level);
-        depth = level;
+        trail = (trail >> up) & ~static_cast<Trail>(1); // now at that level, its pending flag consumed
         left_first = __float_as_uint(nodes[2u * node].w);
         prim_count = __float_as_uint(nodes[2u * node + 1u].w);
         return true;
@@ -276,7 +276,6 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     tr.node = 0; // ex:84: the root's box is never tested
     tr.left_first = __float_as_uint(nodes[0].w);
     tr.prim_count = __float_as_uint(nodes[1].w);
-    tr.depth = 0;
     tr.trail = 0;
     bool alive = true;
     // A traversal visits every node at most once, so `max_steps` (= node count) is never reached on a valid
@@ -298,11 +297,9 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
                 alive = tr.pop(nodes, pair_parent);
             } else { // ex:132-137: descend into the near child, remember the far one
                 tr.node = tr.left_first + (swap ? 1u : 0u);
-                tr.depth += 1;
-                if (t_far < nearest) {
-                    tr.trail |= static_cast<Trail>(1) << tr.depth;
-                    tr.push(tr.left_first + (swap ? 0u : 1u));
-                }
+                const bool pending = t_far < nearest;
+                tr.trail = (tr.trail << 1) | static_cast<Trail>(pending ? 1u : 0u);
+                if (pending) tr.push(tr.left_first + (swap ? 0u : 1u));
                 tr.left_first = __float_as_uint(swap ? rmin.w : lmin.w);
                 tr.prim_count = __float_as_uint(swap ? rmax.w : lmax.w);
             }
