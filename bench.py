@@ -153,7 +153,9 @@ def main():
             return None
         if rehearsal:
             return tiles.gather_slabs(pt.accumulated(), rank, world, args.width, args.height)
-        return tiles.gather_slabs(pt.copy_accumulated_to_device, rank, world, args.width, args.height, device=dev)
+        # slabs go device -> device over xGMI and are de-interleaved on rank 0's GPU: no host copy in the timed region
+        return tiles.gather_slabs(pt.copy_accumulated_to_device, rank, world, args.width, args.height, device=dev,
+                                  keep_on_device=True)
 
     pt.render(args.warmup)
     # prime (untimed) the captured launch shapes the timed K steps will replay: full batches + the remainder
@@ -248,6 +250,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, rng_mode)
     if args.dump and frame is not None:
+        if hasattr(frame, "cpu"):
+            frame = frame.cpu().numpy().reshape(-1, 3)
         rgb = W.tonemap_rgb8(frame, args.steps)
         with open(args.dump, "wb") as f:
             f.write(b"P6\n%d %d\n255\n" % (args.width, args.height))

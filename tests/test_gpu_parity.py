@@ -355,3 +355,29 @@ def test_loop_termination_policies(gpu, orc, max_wavefronts, miss_floor):
     if miss_floor == 10 ** 9:
         assert (pt.accumulated() == spp).all() and len(pt.bounce_table()) == 1
     pt.close(); o.close()
+
+
+def test_device_side_slab_assembly(gpu):
+    """What bench.py does at N > 1 minus the collective: each rank's slab is copied device-to-device into a torch
+    tensor (wfpt_copy_accumulated_to_device) and de-interleaved on the GPU; must equal the unsharded frame."""
+    import torch
+    from wavefront_path_tracer_amd import tiles
+    W = gpu
+    w, h, spp, world = 400, 225, 3, 4
+    full = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL)
+    full.render(spp)
+    ref = full.accumulated()
+    full.close()
+    dev = torch.device("cuda", 0)
+    pad = 3 * max(tiles.slab_pixels(r, world, w, h) for r in range(world))
+    slabs = []
+    for rank in range(world):
+        pt = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=2)
+        pt.render(spp)
+        t = torch.zeros(pad, dtype=torch.float32, device=dev)
+        pt.copy_accumulated_to_device(t.data_ptr(), 12 * tiles.slab_pixels(rank, world, w, h))
+        slabs.append(t)
+        pt.close()
+    frame = tiles.assemble_torch(slabs, w, h)
+    assert frame.is_cuda and tuple(frame.shape) == (h, w, 3)
+    assert_bit_equal(frame.cpu().numpy().reshape(-1, 3), ref, "device-side assembly")

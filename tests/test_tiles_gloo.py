@@ -63,3 +63,22 @@ def test_band_ownership():
         assert max(sizes) - min(sizes) <= 1  # balanced to within one band
     assert tiles.slab_rows(0, 8, 1080) == 8 * 17 and tiles.slab_rows(7, 8, 1080) == 8 * 16
     assert tiles.bands_of(1, 2, 225) == list(range(1, 29, 2))  # 225 rows -> 29 bands, the last one partial
+
+
+def test_torch_assembly_equals_numpy():
+    """The on-device de-interleave bench.py uses (torch strided copies) against the numpy reference, ragged height."""
+    import torch
+    from wavefront_path_tracer_amd import tiles
+    w, h = 40, 100  # 13 bands, the last one partial
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        slabs = [rng.random((tiles.slab_pixels(r, world, w, h), 3), dtype=np.float32) for r in range(world)]
+        want = tiles.assemble(slabs, w, h)
+        pad = 3 * max(tiles.slab_pixels(r, world, w, h) for r in range(world))
+        flat = []
+        for s_ in slabs:
+            t = torch.zeros(pad, dtype=torch.float32)
+            t[:s_.size] = torch.from_numpy(s_.reshape(-1))
+            flat.append(t)
+        got = tiles.assemble_torch(flat, w, h).numpy().reshape(-1, 3)
+        assert np.array_equal(got, want)

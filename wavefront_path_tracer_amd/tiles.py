@@ -38,12 +38,27 @@ def assemble(slabs, width, height):
     return out.reshape(-1, 3)
 
 
-def gather_slabs(local_slab, rank, world, width, height, device=None, group=None):
+def assemble_torch(slabs, width, height):
+    """`assemble` on whatever device the slabs live on: one strided copy per rank, no host round trip.
+    slabs[r] is a flat float32 tensor holding rank r's bands; returns a (height, width, 3) tensor."""
+    import torch
+    world = len(slabs)
+    n_bands = (height + 7) // 8
+    out = torch.empty((n_bands, 8, width, 3), dtype=torch.float32, device=slabs[0].device)
+    for rank, slab in enumerate(slabs):
+        mine = len(bands_of(rank, world, height))
+        if mine:
+            out[rank::world] = slab[:mine * 8 * width * 3].view(mine, 8, width, 3)
+    return out.view(n_bands * 8, width, 3)[:height]
+
+
+def gather_slabs(local_slab, rank, world, width, height, device=None, group=None, keep_on_device=False):
     """One gather of every rank's accumulated slab to rank 0 through torch.distributed.
 
     `local_slab` is either a numpy array (CPU / gloo) or a callable `fill(ptr, n_bytes)` that copies the
     slab into device memory at `ptr` (GPU / RCCL: wfpt_copy_accumulated_to_device). Returns the assembled
-    (width*height, 3) image on rank 0 and None elsewhere.
+    (width*height, 3) image on rank 0 and None elsewhere. With keep_on_device the de-interleave runs on the
+    device the slabs were gathered to and a (height, width, 3) torch tensor is returned (no host copy).
     """
     import torch
     import torch.distributed as dist
@@ -58,10 +73,14 @@ def gather_slabs(local_slab, rank, world, width, height, device=None, group=None
     else:
         send[:mine] = torch.from_numpy(np.ascontiguousarray(local_slab, np.float32).reshape(-1)).to(dev)
     if world == 1:
+        if keep_on_device:
+            return assemble_torch([send], width, height)
         return assemble([send[:mine].cpu().numpy().reshape(-1, 3)], width, height)
     recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
     dist.gather(send, gather_list=recv, dst=0, group=group)
     if rank != 0:
         return None
+    if keep_on_device:
+        return assemble_torch(recv, width, height)
     slabs = [recv[r][:3 * slab_pixels(r, world, width, height)].cpu().numpy().reshape(-1, 3) for r in range(world)]
     return assemble(slabs, width, height)
