@@ -293,6 +293,9 @@ void wfpt_tonemap_rgb8(const float *accumulated, uint32_t n_pixels, uint32_t n_s
  * 5 f32(u32 bits of a)*2^-32, 6 min(a,b), 7 max(a,b)); used by the parity tests to prove the device
  * arithmetic matches the oracle's bit for bit. */
 int wfpt_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+/* Workgroups of the extend kernel that fit one CU when each declares `lds_bytes` of dynamic LDS (occupancy query;
+ * negative status on error). Diagnostic for sizing the LDS-resident scene. */
+int wfpt_debug_extend_blocks_per_cu(int device, uint32_t lds_bytes);
 /* Static facts about the built library, e.g. "gfx950;chunk=512;..." */
 const char *wfpt_build_info(void);
 

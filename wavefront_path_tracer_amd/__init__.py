@@ -153,6 +153,7 @@ def lib():
         "wfpt_tonemap_rgb8": (None, [vp, u32, u32, vp]),
         "wfpt_selftest_math": (i32, [i32, i32, vp, vp, vp, sz]),
         "wfpt_build_info": (C.c_char_p, []),
+        "wfpt_debug_extend_blocks_per_cu": (i32, [i32, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export what wfpt.h declares

@@ -999,6 +999,19 @@ int wfpt_read_totals(wfpt_ctx *c, uint64_t totals[3]) {
     return WFPT_OK;
 }
 
+int wfpt_debug_extend_blocks_per_cu(int device, uint32_t lds_bytes) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return fail(nullptr, WFPT_ERR_NO_DEVICE, "wfpt_debug_extend_blocks_per_cu: no HIP device");
+    WFPT_HIP(nullptr, hipSetDevice(device));
+    SceneDev sc{};
+    sc.lds_scene = 1;
+    sc.lds_bytes = lds_bytes;
+    int blocks = 0;
+    WFPT_HIP(nullptr, extend_blocks_per_cu(sc, &blocks));
+    return blocks;
+}
+
 int wfpt_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n) {
     if (!a || !out) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_selftest_math: null argument");
     int n_dev = 0;

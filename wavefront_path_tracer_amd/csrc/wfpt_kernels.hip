@@ -324,7 +324,11 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
 // LDS_SCENE = false (build extension for scenes larger than a CU's LDS, e.g. BASELINE config 5's 1M-triangle
 // BVH): nodes, primitives and a 32-bit parent table are read from HBM / Infinity Cache through L2 instead.
 template <bool HAS_INACTIVE, typename Trail, int PRIM, bool LDS_SCENE>
-__global__ __launch_bounds__(kExtendThreads) void extend_kernel(ExtendArgs a) {
+#ifndef WFPT_EXTEND_MIN_WAVES
+#define WFPT_EXTEND_MIN_WAVES 8
+#endif
+// min 8 waves per SIMD = 4 workgroups per CU: caps the SGPR count (without it hipcc uses 106 SGPRs and only 3 fit)
+__global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_kernel(ExtendArgs a) {
     extern __shared__ float4 lds[];
     constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u; // float4 per primitive
     float4 *s_nodes = lds;
