@@ -591,6 +591,8 @@ __device__ __forceinline__ float3_ reflect(float3_ r, float3_ n) { // sh:164-166
 // stay packed without a global compaction pass. Extension rays go to slot = logical hit index, which is
 // where ascending-order resolution of sh:155's atomicAdd puts them: the next ray queue is compact and
 // keeps the previous order (neighbouring pixels stay neighbours).
+// (capping the SGPR count with a min-waves launch bound, as extend does, was measured 2 % SLOWER here: the spills cost
+// more than the seventh and eighth wave per SIMD bring)
 __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
     const uint32_t sample = blockIdx.y;
     wfpt_frame_buffer fb = a.ctl->frame;
