@@ -46,9 +46,9 @@ struct wfpt_ctx {
     float *ray_mem[2] = {nullptr, nullptr};
     RayQueue q[2]{};
     int cur = 0; // which queue is "ray_buffer"; the other one is "extension_ray_buffer"
-    float *hit_t = nullptr;
-    uint32_t *hit_prim = nullptr, *hit_ridx = nullptr, *miss_ridx = nullptr, *miss_pixel = nullptr;
-    float *miss_dy = nullptr;
+    uint32_t *hit_mem = nullptr, *miss_mem = nullptr; // 3 planes each: (t, prim, ray index) / (ray index, dir.y, pixel)
+    HitQueue hq{};
+    MissQueue mq{};
     float4 *d_shade_rec = nullptr;
     uint32_t *chunk_hits = nullptr, *chunk_miss = nullptr, *chunk_hit_base = nullptr, *chunk_miss_base = nullptr;
     uint16_t *mat_list = nullptr; // [3][batch][capacity] per-material hit lists
@@ -99,9 +99,8 @@ template <typename T> hipError_t dmalloc(T **p, size_t n) {
 }
 
 void set_queue(RayQueue &q, float *base, size_t cap) {
-    q.ox = base; q.oy = base + cap; q.oz = base + 2 * cap;
-    q.dx = base + 3 * cap; q.dy = base + 4 * cap; q.dz = base + 5 * cap;
-    q.pixel = reinterpret_cast<uint32_t *>(base + 6 * cap);
+    q.base = base;
+    q.cap = static_cast<uint32_t>(cap);
 }
 
 // Geometry of the viewport for this context (band sharding included).
@@ -198,10 +197,8 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.mat_list_mstride = static_cast<size_t>(c->batch_max) * c->capacity;
     a.chunk_mat_mstride = static_cast<size_t>(c->batch_max) * c->n_chunks_max;
     a.q = c->q[qi];
-    a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
-    a.miss_ridx = c->miss_ridx;
-    a.miss_dy = c->miss_dy;
-    a.miss_pixel = c->miss_pixel;
+    a.hq = c->hq;
+    a.mq = c->mq;
     a.chunk_hits = c->chunk_hits;
     a.chunk_miss = c->chunk_miss;
     a.ctl = c->ctl;
@@ -235,7 +232,7 @@ ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit
     a.chunk_mat_mstride = static_cast<size_t>(c->batch_max) * c->n_chunks_max;
     a.q = c->q[qi];
     a.ext = c->q[qi ^ 1];
-    a.hq = {c->hit_t, c->hit_prim, c->hit_ridx};
+    a.hq = c->hq;
     a.chunk_hits = c->chunk_hits; a.chunk_hit_base = c->chunk_hit_base;
     a.image = c->image;
     a.ctl = c->ctl;
@@ -254,9 +251,7 @@ MissArgs miss_args(wfpt_ctx *c, int qi, const uint32_t *n_miss, uint32_t limit, 
     MissArgs a{};
     a.batch = batch_of(c, nb);
     a.q = c->q[qi];
-    a.miss_ridx = c->miss_ridx;
-    a.miss_dy = c->miss_dy;
-    a.miss_pixel = c->miss_pixel;
+    a.mq = c->mq;
     a.chunk_miss = c->chunk_miss; a.chunk_miss_base = c->chunk_miss_base;
     a.image = c->image;
     a.ctl = c->ctl;
@@ -415,12 +410,12 @@ int walk_segments(wfpt_ctx *c, bool hits, uint32_t n, Emit emit) {
     std::vector<uint32_t> ridx(span), prim;
     std::vector<float> t;
     if (span) {
-        WFPT_HIP(c, hipMemcpy(ridx.data(), hits ? c->hit_ridx : c->miss_ridx, sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
+        WFPT_HIP(c, hipMemcpy(ridx.data(), hits ? c->hq.ridx() : c->mq.ridx(), sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
         if (hits) {
             prim.resize(span);
             t.resize(span);
-            WFPT_HIP(c, hipMemcpy(prim.data(), c->hit_prim, sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
-            WFPT_HIP(c, hipMemcpy(t.data(), c->hit_t, sizeof(float) * span, hipMemcpyDeviceToHost));
+            WFPT_HIP(c, hipMemcpy(prim.data(), c->hq.prim(), sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
+            WFPT_HIP(c, hipMemcpy(t.data(), c->hq.t(), sizeof(float) * span, hipMemcpyDeviceToHost));
         }
     }
     for (uint32_t ch = 0; ch < n_chunks; ++ch)
@@ -528,12 +523,10 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         CREATE_HIP(hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * nb * 7 * static_cast<size_t>(c->capacity), c->stream));
         set_queue(c->q[k], c->ray_mem[k], c->capacity);
     }
-    CREATE_HIP(dmalloc(&c->hit_t, nb * c->capacity));
-    CREATE_HIP(dmalloc(&c->hit_prim, nb * c->capacity));
-    CREATE_HIP(dmalloc(&c->hit_ridx, nb * c->capacity));
-    CREATE_HIP(dmalloc(&c->miss_ridx, nb * c->capacity));
-    CREATE_HIP(dmalloc(&c->miss_dy, nb * c->capacity));
-    CREATE_HIP(dmalloc(&c->miss_pixel, nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->hit_mem, 3 * nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->miss_mem, 3 * nb * c->capacity));
+    c->hq = {c->hit_mem, nb * c->capacity};
+    c->mq = {c->miss_mem, nb * c->capacity};
     const size_t n_counts = nb * c->n_chunks_max;
     CREATE_HIP(dmalloc(&c->chunk_hits, n_counts));
     CREATE_HIP(dmalloc(&c->chunk_miss, n_counts));
@@ -682,8 +675,7 @@ void wfpt_destroy(wfpt_ctx *c) {
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
-    void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_t, c->hit_prim, c->hit_ridx, c->miss_ridx, c->miss_dy, c->miss_pixel,
-                    c->d_shade_rec, c->chunk_hits,
+    void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->d_shade_rec, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera,
                     c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,

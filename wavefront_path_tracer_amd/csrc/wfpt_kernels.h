@@ -27,17 +27,35 @@ constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
 constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64
 constexpr int kMaxBatch = 64;      // samples kept in flight by one launch of the device-resident loop
 
-// SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed.
+// SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed. The seven planes of a
+// slice sit `cap` elements apart behind one base pointer (3 SGPRs per queue in a kernel instead of 14).
 struct RayQueue {
-    float *ox, *oy, *oz, *dx, *dy, *dz;
-    uint32_t *pixel;
+    float *base;
+    uint32_t cap;
+    __host__ __device__ float *ox() const { return base; }
+    __host__ __device__ float *oy() const { return base + cap; }
+    __host__ __device__ float *oz() const { return base + 2u * static_cast<size_t>(cap); }
+    __host__ __device__ float *dx() const { return base + 3u * static_cast<size_t>(cap); }
+    __host__ __device__ float *dy() const { return base + 4u * static_cast<size_t>(cap); }
+    __host__ __device__ float *dz() const { return base + 5u * static_cast<size_t>(cap); }
+    __host__ __device__ uint32_t *pixel() const { return reinterpret_cast<uint32_t *>(base + 6u * static_cast<size_t>(cap)); }
 };
 
-// Hit queue (12 B per hit) and miss queue (4 B per miss), segment-compacted.
+// Hit queue (12 B per hit: t, primitive, ray index) and miss queue (12 B per miss: ray index, direction.y, pixel),
+// segment-compacted. Three planes `plane` elements apart behind one base pointer each.
 struct HitQueue {
-    float *t;
-    uint32_t *prim;
-    uint32_t *ridx;
+    uint32_t *base;
+    size_t plane; // elements between planes (= samples in flight * capacity)
+    __host__ __device__ float *t() const { return reinterpret_cast<float *>(base); }
+    __host__ __device__ uint32_t *prim() const { return base + plane; }
+    __host__ __device__ uint32_t *ridx() const { return base + 2u * plane; }
+};
+struct MissQueue {
+    uint32_t *base;
+    size_t plane;
+    __host__ __device__ uint32_t *ridx() const { return base; }
+    __host__ __device__ float *dy() const { return reinterpret_cast<float *>(base + plane); }
+    __host__ __device__ uint32_t *pixel() const { return base + 2u * plane; }
 };
 
 // Device-resident control block. `counters` is the reference's counter_buffer (extend.wgsl:41).
@@ -129,9 +147,7 @@ struct ExtendArgs {
     Batch batch;
     RayQueue q;
     HitQueue hq;
-    uint32_t *miss_ridx;
-    float *miss_dy;       // miss queue payload: direction.y and pixel of the missing ray, so miss_kernel needs no gather
-    uint32_t *miss_pixel;
+    MissQueue mq;         // payload: direction.y and pixel of the missing ray, so miss_kernel needs no gather
     uint32_t *chunk_hits, *chunk_miss;
     Control *ctl;
     const uint32_t *n_in; // rays to trace = min(*n_in, limit)
@@ -184,9 +200,7 @@ struct ShadeArgs {
 struct MissArgs {
     Batch batch;
     RayQueue q;
-    const uint32_t *miss_ridx;
-    const float *miss_dy;
-    const uint32_t *miss_pixel;
+    MissQueue mq;
     const uint32_t *chunk_miss, *chunk_miss_base;
     float *image;
     const Control *ctl;

@@ -33,9 +33,7 @@ __device__ __forceinline__ uint32_t local_pixel(uint32_t pixel, uint32_t width, 
     return ((band / tile.world) * 8u + (y & 7u)) * width + x;
 }
 
-__device__ __forceinline__ RayQueue slice(RayQueue q, size_t off) {
-    return {q.ox + off, q.oy + off, q.oz + off, q.dx + off, q.dy + off, q.dz + off, q.pixel + off};
-}
+__device__ __forceinline__ RayQueue slice(RayQueue q, size_t off) { return {q.base + off, q.cap}; }
 
 // WGSL mat4x4f * vec4f, m column-major: ((c0*x + c1*y) + c2*z) + c3*w per component
 struct float4_ { float x, y, z, w; };
@@ -91,9 +89,9 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
     const uint32_t height = a.true_size ? fb.height : a.gy * 8u;
 
     if (a.true_size && (id_x >= width || id_y >= height)) { // padding lane of a partial tile
-        a.q.ox[idx] = 0.0f; a.q.oy[idx] = 0.0f; a.q.oz[idx] = 0.0f;
-        a.q.dx[idx] = 0.0f; a.q.dy[idx] = 0.0f; a.q.dz[idx] = 0.0f;
-        a.q.pixel[idx] = WFPT_INACTIVE_PIXEL;
+        a.q.ox()[idx] = 0.0f; a.q.oy()[idx] = 0.0f; a.q.oz()[idx] = 0.0f;
+        a.q.dx()[idx] = 0.0f; a.q.dy()[idx] = 0.0f; a.q.dz()[idx] = 0.0f;
+        a.q.pixel()[idx] = WFPT_INACTIVE_PIXEL;
         return;
     }
     const uint32_t pixel_idx = id_x + id_y * width; // gr:57
@@ -126,9 +124,9 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
     // normalize(vec4) (gr:86): length = sqrt(((x*x + y*y) + z*z) + w*w)
     const float len = sqrt_(((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z) + rd.w * rd.w);
 
-    a.q.ox[idx] = origin.x; a.q.oy[idx] = origin.y; a.q.oz[idx] = origin.z;
-    a.q.dx[idx] = rd.x / len; a.q.dy[idx] = rd.y / len; a.q.dz[idx] = rd.z / len;
-    a.q.pixel[idx] = pixel_idx;
+    a.q.ox()[idx] = origin.x; a.q.oy()[idx] = origin.y; a.q.oz()[idx] = origin.z;
+    a.q.dx()[idx] = rd.x / len; a.q.dy()[idx] = rd.y / len; a.q.dz()[idx] = rd.z / len;
+    a.q.pixel()[idx] = pixel_idx;
     if (a.reset_image) { // pt:305-306 folded in: throughput starts at 1
         const uint32_t lp = local_pixel(pixel_idx, width, a.tile);
         a.image[3u * lp + 0u] = 1.0f;
@@ -386,9 +384,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         bool live = idx < n;                               // ex:53
         float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
         if (live) {
-            ox = q.ox[idx]; oy = q.oy[idx]; oz = q.oz[idx];
-            dx = q.dx[idx]; dy = q.dy[idx]; dz = q.dz[idx];
-            if (HAS_INACTIVE) live = q.pixel[idx] != WFPT_INACTIVE_PIXEL;
+            ox = q.ox()[idx]; oy = q.oy()[idx]; oz = q.oz()[idx];
+            dx = q.dx()[idx]; dy = q.dy()[idx]; dz = q.dz()[idx];
+            if (HAS_INACTIVE) live = q.pixel()[idx] != WFPT_INACTIVE_PIXEL;
         }
         float t = 0.0f;
         uint32_t prim = 0;
@@ -435,15 +433,15 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         const size_t seg = qo + static_cast<size_t>(chunk) * kChunk;
         if (hit) { // ex:57-59: payload (t, ray_idx, sphere_idx), slot = rank in thread order
             const size_t slot = seg + hit_before + mbcnt(hit_mask);
-            a.hq.t[slot] = t;
-            a.hq.prim[slot] = prim;
-            a.hq.ridx[slot] = idx;
+            a.hq.t()[slot] = t;
+            a.hq.prim()[slot] = prim;
+            a.hq.ridx()[slot] = idx;
         }
         if (miss) { // ex:61, plus what miss_kernel reads of the ray (mk:29-32)
             const size_t slot = seg + miss_before + mbcnt(miss_mask);
-            a.miss_ridx[slot] = idx;
-            a.miss_dy[slot] = dy;
-            a.miss_pixel[slot] = q.pixel[idx];
+            a.mq.ridx()[slot] = idx;
+            a.mq.dy()[slot] = dy;
+            a.mq.pixel()[slot] = q.pixel()[idx];
         }
         if (threadIdx.x == 0) {
             a.chunk_hits[co + chunk] = hit_total;
@@ -600,8 +598,7 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
     a.ctl += sample;
     a.q = slice(a.q, sample * a.batch.ray_stride);
     a.ext = slice(a.ext, sample * a.batch.ray_stride);
-    a.hq = {a.hq.t + sample * a.batch.queue_stride, a.hq.prim + sample * a.batch.queue_stride,
-            a.hq.ridx + sample * a.batch.queue_stride};
+    a.hq.base += sample * a.batch.queue_stride;
     a.chunk_hits += sample * a.batch.chunk_stride;
     a.chunk_hit_base += sample * a.batch.chunk_stride;
     a.image += sample * a.batch.image_stride;
@@ -626,9 +623,9 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
         float nt = 0.0f;
         if (r0 < count) {
             nr = split ? mat_list[chunk * kChunk + r0] : r0; // rank within the segment's hit queue
-            nt = a.hq.t[chunk * kChunk + nr];
-            nprim = a.hq.prim[chunk * kChunk + nr];
-            nridx = a.hq.ridx[chunk * kChunk + nr];
+            nt = a.hq.t()[chunk * kChunk + nr];
+            nprim = a.hq.prim()[chunk * kChunk + nr];
+            nridx = a.hq.ridx()[chunk * kChunk + nr];
         }
         for (; r0 < count; r0 += kConsumerThreads) {
             const uint32_t r = nr, prim = nprim, ridx = nridx;
@@ -637,9 +634,9 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             if (h >= n_hits) break;
             if (r0 + kConsumerThreads < count) {
                 nr = split ? mat_list[chunk * kChunk + r0 + kConsumerThreads] : r0 + kConsumerThreads;
-                nt = a.hq.t[chunk * kChunk + nr];
-                nprim = a.hq.prim[chunk * kChunk + nr];
-                nridx = a.hq.ridx[chunk * kChunk + nr];
+                nt = a.hq.t()[chunk * kChunk + nr];
+                nprim = a.hq.prim()[chunk * kChunk + nr];
+                nridx = a.hq.ridx()[chunk * kChunk + nr];
             }
             if (split && a.count_out) { // per-material stage of the stage API: counters[2] += rays this stage emits
                 const unsigned long long m = __ballot(true);
@@ -651,9 +648,9 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
                          rec2 = a.scene.shade_rec[3u * prim + 2u];
             const uint32_t mat_type = __float_as_uint(rec2.x);
             struct { float albedo[3]; float fuzz, refract_index; } mat = {{rec1.x, rec1.y, rec1.z}, rec0.w, rec1.w};
-            const float ox = a.q.ox[ridx], oy = a.q.oy[ridx], oz = a.q.oz[ridx];
-            const float dx = a.q.dx[ridx], dy = a.q.dy[ridx], dz = a.q.dz[ridx];
-            const uint32_t pixel_idx = a.q.pixel[ridx];
+            const float ox = a.q.ox()[ridx], oy = a.q.oy()[ridx], oz = a.q.oz()[ridx];
+            const float dx = a.q.dx()[ridx], dy = a.q.dy()[ridx], dz = a.q.dz()[ridx];
+            const uint32_t pixel_idx = a.q.pixel()[ridx];
             // sh:84-87: throughput *= albedo, for every material type (load now, store after the scatter math)
             const uint32_t lp = local_pixel(pixel_idx, a.image_width, a.tile);
             float *px = a.image + 3u * static_cast<size_t>(lp);
@@ -716,9 +713,9 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
                 if (sqrt_(dot3(ext, ext)) < 0.001f) ext = nrm;
             }
             // sh:153-155: direction is NOT normalised; invDirection is recomputed by extend
-            a.ext.ox[h] = p_x; a.ext.oy[h] = p_y; a.ext.oz[h] = p_z;
-            a.ext.dx[h] = ext.x; a.ext.dy[h] = ext.y; a.ext.dz[h] = ext.z;
-            a.ext.pixel[h] = pixel_idx;
+            a.ext.ox()[h] = p_x; a.ext.oy()[h] = p_y; a.ext.oz()[h] = p_z;
+            a.ext.dx()[h] = ext.x; a.ext.dy()[h] = ext.y; a.ext.dz()[h] = ext.z;
+            a.ext.pixel()[h] = pixel_idx;
             px[0] = thr_r * mat.albedo[0];
             px[1] = thr_g * mat.albedo[1];
             px[2] = thr_b * mat.albedo[2];
@@ -733,8 +730,7 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
     const uint32_t sample = blockIdx.y;
     a.ctl += sample;
     a.q = slice(a.q, sample * a.batch.ray_stride);
-    a.miss_dy += sample * a.batch.queue_stride;
-    a.miss_pixel += sample * a.batch.queue_stride;
+    a.mq.base += sample * a.batch.queue_stride;
     a.chunk_miss += sample * a.batch.chunk_stride;
     a.chunk_miss_base += sample * a.batch.chunk_stride;
     a.image += sample * a.batch.image_stride;
@@ -748,16 +744,16 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
         float ndy = 0.0f;
         uint32_t npix = 0;
         if (threadIdx.x < count) {
-            ndy = a.miss_dy[chunk * kChunk + threadIdx.x]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
-            npix = a.miss_pixel[chunk * kChunk + threadIdx.x];
+            ndy = a.mq.dy()[chunk * kChunk + threadIdx.x]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
+            npix = a.mq.pixel()[chunk * kChunk + threadIdx.x];
         }
         for (uint32_t r = threadIdx.x; r < count; r += kConsumerThreads) {
             if (base + r >= n_miss) break;
             const float dy = ndy;
             const uint32_t pixel_idx = npix;
             if (r + kConsumerThreads < count) {
-                ndy = a.miss_dy[chunk * kChunk + r + kConsumerThreads];
-                npix = a.miss_pixel[chunk * kChunk + r + kConsumerThreads];
+                ndy = a.mq.dy()[chunk * kChunk + r + kConsumerThreads];
+                npix = a.mq.pixel()[chunk * kChunk + r + kConsumerThreads];
             }
             const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
             const float om = 1.0f - t;
@@ -827,9 +823,9 @@ __global__ void rays_to_aos_kernel(RayQueue q, wfpt_ray *out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     wfpt_ray r;
-    const uint32_t pixel = q.pixel[i];
-    r.origin[0] = q.ox[i]; r.origin[1] = q.oy[i]; r.origin[2] = q.oz[i];
-    r.direction[0] = q.dx[i]; r.direction[1] = q.dy[i]; r.direction[2] = q.dz[i];
+    const uint32_t pixel = q.pixel()[i];
+    r.origin[0] = q.ox()[i]; r.origin[1] = q.oy()[i]; r.origin[2] = q.oz()[i];
+    r.direction[0] = q.dx()[i]; r.direction[1] = q.dy()[i]; r.direction[2] = q.dz()[i];
     r.direction[3] = 0.0f;
     if (pixel == WFPT_INACTIVE_PIXEL) { // padding rays are all-zero in the reference layout
         r.origin[3] = 0.0f;
@@ -848,9 +844,9 @@ __global__ void rays_from_aos_kernel(RayQueue q, const wfpt_ray *in, uint32_t n)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const wfpt_ray r = in[i];
-    q.ox[i] = r.origin[0]; q.oy[i] = r.origin[1]; q.oz[i] = r.origin[2];
-    q.dx[i] = r.direction[0]; q.dy[i] = r.direction[1]; q.dz[i] = r.direction[2];
-    q.pixel[i] = r.pixel_idx;
+    q.ox()[i] = r.origin[0]; q.oy()[i] = r.origin[1]; q.oz()[i] = r.origin[2];
+    q.dx()[i] = r.direction[0]; q.dy()[i] = r.direction[1]; q.dz()[i] = r.direction[2];
+    q.pixel()[i] = r.pixel_idx;
 }
 
 __global__ void selftest_math_kernel(int op, const float *a, const float *b, float *out, size_t n) {
