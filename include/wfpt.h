@@ -288,6 +288,15 @@ int wfpt_read_totals(wfpt_ctx *ctx, uint64_t totals[3]);
 /* display_shader.wgsl:50-52 tone map, sqrt(acc / n_samples) -> 8-bit RGB (host side, for image dumps) */
 void wfpt_tonemap_rgb8(const float *accumulated, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb);
 
+/* Image output, the step right after the path (the reference presents through a fullscreen pass, display.rs:112-150,
+ * display_shader.wgsl:44-55; here the frame goes to a file). Both read the accumulated image of this context and
+ * divide by wfpt_accumulated_samples. Rows are written top to bottom as stored (pixel_idx = x + y*width).
+ *   wfpt_save_ppm: binary P6, 8-bit, sqrt(acc / n) exactly like display_shader.wgsl:50-52.
+ *   wfpt_save_pfm: binary PF, linear f32 acc / n (PFM stores rows bottom-up, so rows are flipped on write).
+ * Contexts created with tile sharding hold only their own bands and are refused. */
+int wfpt_save_ppm(wfpt_ctx *ctx, const char *path);
+int wfpt_save_pfm(wfpt_ctx *ctx, const char *path);
+
 /* ------------------------------------------------------------------ diagnostics */
 /* Runs the device math primitives over arrays (op: 0 sqrt(a), 1 a/b, 2 sin(a), 3 cos(a), 4 pow(a,b),
  * 5 f32(u32 bits of a)*2^-32, 6 min(a,b), 7 max(a,b)); used by the parity tests to prove the device

@@ -381,3 +381,47 @@ def test_device_side_slab_assembly(gpu):
     frame = tiles.assemble_torch(slabs, w, h)
     assert frame.is_cuda and tuple(frame.shape) == (h, w, 3)
     assert_bit_equal(frame.cpu().numpy().reshape(-1, 3), ref, "device-side assembly")
+
+
+def test_image_output(gpu, orc, tmp_path):
+    """the frame right after the path, as PPM (display_shader.wgsl:50-52 tone map) and PFM."""
+    W = gpu
+    w, h, spp = 96, 40, 3
+    pt = make_tracer(W, "simple", w, h, max_wavefronts=4)
+    with pytest.raises(W.WfptError):
+        pt.save_ppm(tmp_path / "early.ppm")  # nothing accumulated yet
+    pt.render(spp)
+    acc = pt.accumulated()
+    pt.save_ppm(tmp_path / "f.ppm")
+    pt.save_pfm(tmp_path / "f.pfm")
+    raw = (tmp_path / "f.ppm").read_bytes()
+    head = b"P6\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(head)
+    rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(-1, 3)
+    assert np.array_equal(rgb, orc.tonemap_rgb8(acc, spp))
+    pfm = (tmp_path / "f.pfm").read_bytes()
+    head = b"PF\n%d %d\n-1.0\n" % (w, h)
+    assert pfm.startswith(head)
+    lin = np.frombuffer(pfm[len(head):], "<f4").reshape(h, w, 3)[::-1]  # PFM rows are bottom-up
+    assert_bit_equal(np.ascontiguousarray(lin).reshape(-1, 3), (np.float32(1.0) / np.float32(spp)) * acc, "PFM")
+    tiled = make_tracer(W, "simple", w, h, tile_rank=0, tile_world=2)
+    tiled.render(1)
+    with pytest.raises(W.WfptError):
+        tiled.save_ppm(tmp_path / "t.ppm")  # a sharded context holds only its bands
+    tiled.close(); pt.close()
+
+
+@pytest.mark.parametrize("w,h", [(2880, 1620), (3840, 2160)])  # main.rs:33: the shipped default and the commented 4K size
+def test_large_frames(gpu, orc, w, h):
+    """The reference's own frame sizes: 4.7 M and 8.3 M rays per wavefront, 16 samples in flight (multi-GB queues).
+    One batch of 16 samples + 1 single sample against the oracle's bounce tables and image, bit for bit."""
+    W = gpu
+    bounces, spp = 4, 17
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces)
+    pt.render(spp)
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+    o.render(spp)
+    assert np.array_equal(pt.bounce_table(), o.bounce_table())
+    assert np.array_equal(pt.totals(), o.totals())
+    assert_bit_equal(pt.accumulated(), o.accumulated(), f"{w}x{h}")
+    pt.close(); o.close()

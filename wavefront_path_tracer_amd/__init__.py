@@ -153,6 +153,8 @@ def lib():
         "wfpt_tonemap_rgb8": (None, [vp, u32, u32, vp]),
         "wfpt_selftest_math": (i32, [i32, i32, vp, vp, vp, sz]),
         "wfpt_build_info": (C.c_char_p, []),
+        "wfpt_save_ppm": (i32, [vp, C.c_char_p]),
+        "wfpt_save_pfm": (i32, [vp, C.c_char_p]),
         "wfpt_debug_extend_blocks_per_cu": (i32, [i32, u32]),
     }
     for name, (res, args) in sig.items():
@@ -641,6 +643,14 @@ class PathTracer:
         a = np.zeros(n, "<u4")
         self._check(lib().wfpt_read_misses(self.handle, _p(a), n))
         return a
+
+    def save_ppm(self, path):
+        """8-bit P6 of sqrt(accumulated / samples), the display shader's tone map (display_shader.wgsl:50-52)."""
+        self._check(lib().wfpt_save_ppm(self.handle, os.fsencode(path)))
+
+    def save_pfm(self, path):
+        """Linear float32 PFM of accumulated / samples."""
+        self._check(lib().wfpt_save_pfm(self.handle, os.fsencode(path)))
 
     def bounce_table(self):
         t = np.zeros((64, 4), "<u4")

@@ -991,6 +991,44 @@ int wfpt_read_totals(wfpt_ctx *c, uint64_t totals[3]) {
     return WFPT_OK;
 }
 
+static int read_frame(wfpt_ctx *c, std::vector<float> &acc, const char *who) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, std::string(who) + ": null argument");
+    if (c->tile.world > 1) return fail(c, WFPT_ERR_UNSUPPORTED, std::string(who) + ": this context holds only its own pixel bands");
+    if (c->accumulated_samples == 0) return fail(c, WFPT_ERR_INVALID_ARGUMENT, std::string(who) + ": nothing accumulated yet");
+    acc.resize(3 * static_cast<size_t>(c->n_pixels));
+    return wfpt_read_accumulated(c, acc.data(), acc.size());
+}
+
+int wfpt_save_ppm(wfpt_ctx *c, const char *path) {
+    std::vector<float> acc;
+    if (int r = read_frame(c, acc, "wfpt_save_ppm"); r != WFPT_OK) return r;
+    if (!path) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_ppm: null path");
+    std::vector<uint8_t> rgb(acc.size());
+    wfpt_tonemap_rgb8(acc.data(), c->n_pixels, c->accumulated_samples, rgb.data());
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(c, WFPT_ERR_INVALID_ARGUMENT, std::string("wfpt_save_ppm: cannot open ") + path);
+    std::fprintf(f, "P6\n%u %u\n255\n", c->width, c->height);
+    const bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    std::fclose(f);
+    return ok ? WFPT_OK : fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_ppm: short write");
+}
+
+int wfpt_save_pfm(wfpt_ctx *c, const char *path) {
+    std::vector<float> acc;
+    if (int r = read_frame(c, acc, "wfpt_save_pfm"); r != WFPT_OK) return r;
+    if (!path) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_pfm: null path");
+    const float inv_n = 1.0f / static_cast<float>(c->accumulated_samples);
+    for (float &v : acc) v = inv_n * v; // display_shader.wgsl:50: invN * color, before the sqrt
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(c, WFPT_ERR_INVALID_ARGUMENT, std::string("wfpt_save_pfm: cannot open ") + path);
+    std::fprintf(f, "PF\n%u %u\n-1.0\n", c->width, c->height); // negative scale = little-endian
+    bool ok = true;
+    const size_t row = 3 * static_cast<size_t>(c->width);
+    for (uint32_t y = c->height; y-- > 0 && ok;) ok = std::fwrite(acc.data() + y * row, sizeof(float), row, f) == row;
+    std::fclose(f);
+    return ok ? WFPT_OK : fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_pfm: short write");
+}
+
 int wfpt_debug_extend_blocks_per_cu(int device, uint32_t lds_bytes) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
