@@ -192,6 +192,11 @@ void wfpt_gpu_camera_new(const float position[3], float pitch, float yaw, float 
                          float focus_distance, wfpt_gpu_camera *out);
 /* f32::to_radians */
 float wfpt_to_radians(float degrees);
+/* camera_controller.rs:125-158 (CameraController::update_camera): moves the camera by the pressed-key amounts
+ * {forward, backward, right, left, up, down} and the pending mouse rotation {horizontal, vertical} over dt seconds,
+ * clamps the pitch to +-(pi - 0.001), and zeroes `rotate` like the reference does. */
+void wfpt_camera_controller_update(float position[3], float *pitch, float *yaw, const float amounts[6],
+                                   float rotate[2], float speed, float sensitivity, float dt);
 /* path_tracer.rs:282-289. The reference panics for x <= 64; this returns (1,1) there. */
 void wfpt_workgroup_size_64(uint32_t x, uint32_t *gx, uint32_t *gy);
 /* kernel.rs:32: shader basename -> stage; -1 if unknown */

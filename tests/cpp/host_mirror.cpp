@@ -1,6 +1,7 @@
 // Exercises the C++ host mirror (wavefront_path_tracer_amd/host/wfpt.hpp) the way the reference's main.rs +
 // PathTracer are used (gpu_wavefront_pt/src/main.rs:17-36, path_tracer.rs:279-371).
 //   host_mirror model <out.bin>                         scene + BVH + camera bytes (no GPU needed)
+//   host_mirror controller -                            interactive camera controller + change flags
 //   host_mirror run <w> <h> <spp> <bounces> <out.bin>   host-driven PathTracer::run() x spp
 //   host_mirror render <w> <h> <spp> <bounces> <out.bin> device-resident loop
 #include <cstdio>
@@ -35,6 +36,22 @@ int main(int argc, char **argv) {
             fclose(f);
             const auto g = wfpt::workgroup_size_64(2073600);
             printf("%zu %zu %u %u\n", scene.spheres.size(), tree.nodes.size(), g.first, g.second);
+            return 0;
+        }
+        if (mode == "controller") { // camera_controller.rs:74-158 + parameters.rs:51-57, printed as raw f32 bits
+            wfpt::RenderParameters rp(cc, {640u, 360u});
+            wfpt::CameraController moved = rp.camera_controller();
+            moved.move_forward(1); moved.move_left(1); moved.move_up(1);
+            moved.process_mouse({3.0f, -2.0f});
+            moved.update_camera(0.25f);
+            moved.set_vfov(40.0f);
+            rp.update_camera_controller(moved);
+            const wfpt::Camera &c = rp.camera_controller().camera();
+            const float v[6] = {c.position[0], c.position[1], c.position[2], c.pitch, c.yaw, rp.camera_controller().vfov_rad()};
+            uint32_t u[6];
+            memcpy(u, v, sizeof v);
+            printf("%08x %08x %08x %08x %08x %08x %d %d\n", u[0], u[1], u[2], u[3], u[4], u[5], rp.camera_changed() ? 1 : 0,
+                   rp.resized() ? 1 : 0);
             return 0;
         }
         if (argc < 7) return 2;

@@ -33,6 +33,19 @@ def test_cpp_data_model_matches_oracle(exe, orc, tmp_path):
     assert out.read_bytes() == want
 
 
+def test_cpp_camera_controller(exe, wf):
+    """The C++ and Python mirrors of CameraController (camera_controller.rs:74-158) agree to the bit."""
+    r = subprocess.run([exe, "controller", "-"], capture_output=True, text=True, check=True)
+    cc = wf.CameraController(wf.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
+    cc.move_forward(1); cc.move_left(1); cc.move_up(1)
+    cc.process_mouse((3.0, -2.0))
+    cc.update_camera(0.25)
+    cc.set_vfov(40.0)
+    vals = np.array(list(cc.camera.position) + [cc.camera.pitch, cc.camera.yaw, cc.vfov_rad()], "<f4")
+    want = [f"{u:08x}" for u in vals.view("<u4")] + ["1", "0"]
+    assert r.stdout.split() == want
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["run", "render"])
 def test_cpp_path_tracer(gpu, exe, orc, tmp_path, mode):

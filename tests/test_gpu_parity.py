@@ -146,6 +146,40 @@ def test_per_material_split_is_identical(gpu, orc):
         a.close(); b.close()
 
 
+def test_interactive_camera_resets_accumulation(gpu, orc):
+    """path_tracer.rs:231-277: a moved camera (camera_controller.rs:125-158) or a resized viewport marks the render
+    parameters changed; the next run() re-uploads camera / matrices, clears the accumulation and restarts at frame 1,
+    so the image equals a fresh render from the new pose."""
+    W = gpu
+    w, h = 400, 224
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=4, spp=2)
+    pt.run(); pt.run()
+    assert pt.render_progress.accumulated_samples() == 2
+    rp = pt.get_render_parameters()
+    cc = rp.camera_controller().copy()
+    cc.move_forward(1); cc.move_up(1); cc.process_mouse((5.0, 1.0))
+    cc.update_camera(0.5)
+    rp.update_camera_controller(cc)
+    assert rp.changed() and rp.camera_changed() and not rp.resized()
+    pt.update_render_parameters(rp)
+    pt.run(); pt.run()
+    assert pt.render_progress.accumulated_samples() == 2 and not rp.changed()
+    # the oracle rendered from the moved pose
+    view = cc.get_view_matrix()
+    cam = cc.get_GPU_camera()
+    sp, mt, nodes, cam0, _, _ = inputs_for(orc, "shirley", w, h)
+    proj = W.ProjectionMatrix(cc.vfov_rad(), np.float32(w) / np.float32(h), *cc.get_clip_planes()).p_inv()
+    o = make_oracle(orc, (sp, mt, nodes, cam.view(cam0.dtype), proj, view), w, h, max_wavefronts=4)
+    o.render(2)
+    assert_bit_equal(pt.accumulated(), o.accumulated(), "after the camera moved")
+    # resize: new viewport, same rule
+    rp.set_viewport((200, 120))
+    pt.resize(rp)
+    pt.run()
+    assert pt.n_pixels == 200 * 120 and pt.render_progress.accumulated_samples() == 1
+    pt.close(); o.close()
+
+
 def test_tile_sharding_pixel_mode(gpu, orc):
     """Bands of 8 rows dealt round-robin to `world` contexts reproduce the unsharded image in PIXEL mode."""
     from wavefront_path_tracer_amd import tiles

@@ -95,6 +95,47 @@ def test_render_parameters_and_progress(wf):
     assert f.into_array() == [800, 600, 1, 7]
 
 
+def test_camera_controller_update(wf):
+    """camera_controller.rs:74-158: key amounts, mouse rotation, pitch clamp; f32 arithmetic restated with numpy."""
+    f = np.float32
+    cc = wf.CameraController(wf.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
+    p0, pitch0, yaw0 = cc.camera.position.copy(), f(cc.camera.pitch), f(cc.camera.yaw)
+    cc.move_forward(1); cc.move_left(1); cc.move_up(1); cc.move_down(0)
+    cc.process_mouse((3.0, -2.0))
+    dt = f(0.25)
+    cc.update_camera(float(dt))
+    sy, cy = f(np.sin(yaw0, dtype=np.float32)), f(np.cos(yaw0, dtype=np.float32))
+    fwd, right = np.array([sy, 0, cy], "<f4"), np.array([-cy, 0, sy], "<f4")
+    want = p0 + fwd * f(1.0) * f(4.0) * dt
+    want = want + right * f(-1.0) * f(4.0) * dt
+    want[1] += f(1.0) * f(4.0) * dt
+    assert np.allclose(cc.camera.position, want, rtol=0, atol=1e-6)
+    assert cc.camera.yaw == pytest.approx(float(yaw0 - f(3.0) * f(0.1) * dt), abs=1e-7)
+    assert cc.camera.pitch == pytest.approx(float(pitch0 + f(2.0) * f(0.1) * dt), abs=1e-7)
+    # the rotation is consumed (camera_controller.rs:143-147): a second update only translates
+    yaw1 = cc.camera.yaw
+    cc.update_camera(0.25)
+    assert cc.camera.yaw == yaw1
+    # releasing the keys stops the motion
+    for m in (cc.move_forward, cc.move_left, cc.move_up):
+        m(0)
+    p1 = cc.camera.position.copy()
+    cc.update_camera(1.0)
+    assert np.array_equal(cc.camera.position, p1)
+    # pitch clamp at +-(pi - 0.001)
+    cc.process_mouse((0.0, -1e6)); cc.update_camera(1.0)
+    assert cc.camera.pitch == pytest.approx(np.pi - 0.001, abs=1e-6)
+    cc.process_mouse((0.0, 1e6)); cc.update_camera(1.0)
+    assert cc.camera.pitch == pytest.approx(-(np.pi - 0.001), abs=1e-6)
+    # setters (camera_controller.rs:55, 60-61) and the Copy semantics hosts rely on
+    cc.set_vfov(40.0); cc.set_defocus_angle(1.0); cc.set_focus_distance(7.5)
+    assert cc.vfov_rad() == pytest.approx(np.radians(40.0), rel=1e-6)
+    assert cc.dof() == (pytest.approx(np.radians(1.0), rel=1e-6), 7.5)
+    other = cc.copy()
+    other.move_up(1); other.update_camera(1.0)
+    assert other.camera.position[1] != cc.camera.position[1]
+
+
 def test_tonemap(wf, orc):
     acc = np.array([[0.0, 4.0, 16.0], [1.0, 100.0, 2.25]], "<f4")
     got = wf.tonemap_rgb8(acc, 4)  # sqrt(acc / 4) -> 0, 1, 2->clamp, .5, clamp, .75

@@ -113,6 +113,7 @@ def lib():
         "wfpt_p_inv": (None, [f32, f32, f32, f32, vp]),
         "wfpt_gpu_camera_new": (None, [vp, f32, f32, f32, f32, vp]),
         "wfpt_to_radians": (f32, [f32]),
+        "wfpt_camera_controller_update": (None, [vp, C.POINTER(f32), C.POINTER(f32), vp, vp, f32, f32, f32]),
         "wfpt_workgroup_size_64": (None, [u32, C.POINTER(u32), C.POINTER(u32)]),
         "wfpt_stage_from_name": (i32, [C.c_char_p]),
         "wfpt_stage_name": (C.c_char_p, [i32]),
@@ -300,7 +301,7 @@ class Camera:
 
 
 class CameraController:
-    """wavefront_common/src/camera_controller.rs:8-72 (the interactive half is out of scope)."""
+    """wavefront_common/src/camera_controller.rs:8-158"""
 
     def __init__(self, camera, vfov, defocus_angle, focus_distance, z_near, z_far, speed=4.0, sensitivity=0.1):
         L = lib()
@@ -310,12 +311,64 @@ class CameraController:
         self.focus_distance = focus_distance
         self.z_near, self.z_far = z_near, z_far
         self.speed, self.sensitivity = speed, sensitivity
+        self._amounts = np.zeros(6, "<f4")  # forward, backward, right, left, up, down
+        self._rotate = np.zeros(2, "<f4")   # horizontal, vertical
+
+    def copy(self):
+        """The reference's controller is `Copy`; hosts edit a copy and hand it to update_camera_controller."""
+        other = CameraController.__new__(CameraController)
+        other.__dict__.update(self.__dict__)
+        cam = Camera.__new__(Camera)
+        cam.position, cam.pitch, cam.yaw = self.camera.position.copy(), self.camera.pitch, self.camera.yaw
+        other.camera, other._amounts, other._rotate = cam, self._amounts.copy(), self._rotate.copy()
+        return other
 
     def vfov_rad(self):
         return self._vfov_rad
 
+    def set_vfov(self, vfov):
+        self._vfov_rad = lib().wfpt_to_radians(vfov)
+
     def dof(self):
         return self.defocus_angle_rad, self.focus_distance
+
+    def set_defocus_angle(self, defocus_angle):
+        self.defocus_angle_rad = lib().wfpt_to_radians(defocus_angle)
+
+    def set_focus_distance(self, focus_distance):
+        self.focus_distance = focus_distance
+
+    def process_mouse(self, delta):
+        """camera_controller.rs:74-77"""
+        self._rotate[:] = delta
+
+    def _press(self, slot, direction):
+        self._amounts[slot] = 1.0 if direction == 1 else 0.0
+
+    def move_forward(self, direction):  # camera_controller.rs:95-101
+        self._press(0, direction)
+
+    def move_backwards(self, direction):  # :103-109
+        self._press(1, direction)
+
+    def move_right(self, direction):  # :111-117
+        self._press(2, direction)
+
+    def move_left(self, direction):  # :119-125
+        self._press(3, direction)
+
+    def move_up(self, direction):  # :79-85
+        self._press(4, direction)
+
+    def move_down(self, direction):  # :87-93
+        self._press(5, direction)
+
+    def update_camera(self, dt):
+        """camera_controller.rs:125-158"""
+        pitch, yaw = C.c_float(self.camera.pitch), C.c_float(self.camera.yaw)
+        lib().wfpt_camera_controller_update(_p(self.camera.position), C.byref(pitch), C.byref(yaw), _p(self._amounts),
+                                            _p(self._rotate), self.speed, self.sensitivity, dt)
+        self.camera.pitch, self.camera.yaw = pitch.value, yaw.value
 
     def get_clip_planes(self):
         return self.z_near, self.z_far
@@ -354,6 +407,12 @@ class RenderParameters:
 
     def changed(self):
         return self._resized or self._camera_changed
+
+    def resized(self):
+        return self._resized
+
+    def camera_changed(self):
+        return self._camera_changed
 
     def set_viewport(self, size):
         self._viewport_size = tuple(size)

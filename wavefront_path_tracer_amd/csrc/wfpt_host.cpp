@@ -373,6 +373,22 @@ void wfpt_gpu_camera_new(const float pos[3], float pitch, float yaw, float defoc
 
 float wfpt_to_radians(float deg) { return deg * 0.017453292519943295769236907684886f; }
 
+void wfpt_camera_controller_update(float position[3], float *pitch, float *yaw, const float amounts[6], float rotate[2],
+                                   float speed, float sensitivity, float dt) { // camera_controller.rs:125-158
+    const float sin_yaw = std::sin(*yaw), cos_yaw = std::cos(*yaw);
+    const float forward[3] = {sin_yaw, 0.0f, cos_yaw}, right[3] = {-cos_yaw, 0.0f, sin_yaw};
+    const float fb = amounts[0] - amounts[1], rl = amounts[2] - amounts[3];
+    for (int k = 0; k < 3; ++k) position[k] += forward[k] * fb * speed * dt; // :131
+    for (int k = 0; k < 3; ++k) position[k] += right[k] * rl * speed * dt;   // :132
+    position[1] += (amounts[4] - amounts[5]) * speed * dt;                   // :137: no roll, so y moves directly
+    *yaw -= rotate[0] * sensitivity * dt;                                    // :140-141
+    *pitch -= rotate[1] * sensitivity * dt;
+    rotate[0] = rotate[1] = 0.0f;                                            // :146-147
+    const float safe = 3.14159265358979323846f - 0.001f;                     // SAFE_FRAC_PI, :29
+    if (*pitch < -safe) *pitch = -safe;
+    else if (*pitch > safe) *pitch = safe;
+}
+
 void wfpt_workgroup_size_64(uint32_t x, uint32_t *gx, uint32_t *gy) { // path_tracer.rs:282-289
     const uint32_t groups = x / 64u + (x % 64u ? 1u : 0u); // div_ceil
     if (groups <= 1) { *gx = 1; *gy = 1; return; }         // the reference unwraps None and panics here

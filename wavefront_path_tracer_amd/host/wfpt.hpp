@@ -83,7 +83,7 @@ struct Camera {
     }
 };
 
-// wavefront_common/src/camera_controller.rs:8-72 (the interactive half is out of scope)
+// wavefront_common/src/camera_controller.rs:8-158
 class CameraController {
   public:
     CameraController(Camera camera, float vfov, float defocus_angle, float focus_distance, float z_near, float z_far,
@@ -91,7 +91,22 @@ class CameraController {
         : camera_(camera), vfov_rad_(wfpt_to_radians(vfov)), defocus_angle_rad_(wfpt_to_radians(defocus_angle)),
           focus_distance_(focus_distance), z_near_(z_near), z_far_(z_far), speed_(speed), sensitivity_(sensitivity) {}
     float vfov_rad() const { return vfov_rad_; }
+    void set_vfov(float vfov) { vfov_rad_ = wfpt_to_radians(vfov); }
     std::pair<float, float> dof() const { return {defocus_angle_rad_, focus_distance_}; }
+    void set_defocus_angle(float da) { defocus_angle_rad_ = wfpt_to_radians(da); }
+    void set_focus_distance(float fd) { focus_distance_ = fd; }
+    // camera_controller.rs:74-125: key state and pending mouse rotation
+    void process_mouse(std::array<float, 2> delta) { rotate_ = delta; }
+    void move_forward(uint32_t dir) { amounts_[0] = dir == 1 ? 1.0f : 0.0f; }
+    void move_backwards(uint32_t dir) { amounts_[1] = dir == 1 ? 1.0f : 0.0f; }
+    void move_right(uint32_t dir) { amounts_[2] = dir == 1 ? 1.0f : 0.0f; }
+    void move_left(uint32_t dir) { amounts_[3] = dir == 1 ? 1.0f : 0.0f; }
+    void move_up(uint32_t dir) { amounts_[4] = dir == 1 ? 1.0f : 0.0f; }
+    void move_down(uint32_t dir) { amounts_[5] = dir == 1 ? 1.0f : 0.0f; }
+    void update_camera(float dt) { // camera_controller.rs:125-158
+        wfpt_camera_controller_update(camera_.position.data(), &camera_.pitch, &camera_.yaw, amounts_.data(), rotate_.data(),
+                                      speed_, sensitivity_, dt);
+    }
     std::pair<float, float> get_clip_planes() const { return {z_near_, z_far_}; }
     wfpt_gpu_camera get_GPU_camera() const { // camera_controller.rs:66-68
         wfpt_gpu_camera c{};
@@ -104,6 +119,8 @@ class CameraController {
   private:
     Camera camera_;
     float vfov_rad_, defocus_angle_rad_, focus_distance_, z_near_, z_far_, speed_, sensitivity_;
+    std::array<float, 6> amounts_{}; // forward, backward, right, left, up, down
+    std::array<float, 2> rotate_{};  // horizontal, vertical
 };
 
 // wavefront_common/src/projection_matrix.rs
@@ -122,6 +139,8 @@ class RenderParameters {
   public:
     RenderParameters(CameraController cc, std::pair<uint32_t, uint32_t> viewport) : cc_(cc), viewport_(viewport) {}
     bool changed() const { return resized_ || camera_changed_; }
+    bool resized() const { return resized_; }
+    bool camera_changed() const { return camera_changed_; }
     void set_viewport(std::pair<uint32_t, uint32_t> size) { viewport_ = size; resized_ = true; }
     std::pair<uint32_t, uint32_t> viewport_size() const { return viewport_; }
     void reset() { resized_ = camera_changed_ = false; }
