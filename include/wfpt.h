@@ -178,6 +178,16 @@ int wfpt_build_bvh(wfpt_sphere *spheres, uint32_t n_spheres, wfpt_bvh_node *node
  * number of bins per axis (bvh.rs:4's 4096 is O(10^10) work for a million primitives). Reorders in place. */
 int wfpt_build_bvh_triangles(wfpt_triangle *triangles, uint32_t n_triangles, wfpt_bvh_node *nodes,
                              uint32_t node_capacity, uint32_t *n_nodes, uint32_t n_bins);
+/* Build extension: the same two builders ON THE DEVICE (csrc/wfpt_bvh_build.hip). Same
+ * arguments, same results byte for byte -- node array in bvh.rs's depth-first numbering, primitives reordered in
+ * place -- so either can feed wfpt_create / wfpt_create_mesh. `device` is the HIP device ordinal; `device_ms`
+ * (may be NULL) receives the time between the first and the last build kernel (host<->device copies of the
+ * inputs / outputs excluded). WFPT_ERR_NO_DEVICE without a GPU: there is no silent fall back to the host builder. */
+int wfpt_build_bvh_device(wfpt_sphere *spheres, uint32_t n_spheres, wfpt_bvh_node *nodes, uint32_t node_capacity,
+                          uint32_t *n_nodes, int device, float *device_ms);
+int wfpt_build_bvh_triangles_device(wfpt_triangle *triangles, uint32_t n_triangles, wfpt_bvh_node *nodes,
+                                    uint32_t node_capacity, uint32_t *n_nodes, uint32_t n_bins, int device,
+                                    float *device_ms);
 /* BASELINE config 5: seeded triangle soup -- centres U[-10,10]^3, edges U[-0.05,0.05]^3, material i % 3 over
  * {Lambertian 0.7, Metal 0.8 fuzz 0.1, Dielectric 1.5}. Writes n triangles and 3 materials; returns 3. */
 uint32_t wfpt_scene_random_mesh(uint64_t seed, uint32_t n_triangles, wfpt_triangle *triangles, wfpt_material *materials);

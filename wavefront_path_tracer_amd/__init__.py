@@ -54,6 +54,9 @@ TRIANGLE = np.dtype([("v0", "<f4", 3), ("material_idx", "<u4"), ("e1", "<f4", 3)
                      ("e2", "<f4", 3), ("_pad", "<u4")])
 
 
+OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5  # wfpt_status
+
+
 class WfptError(RuntimeError):
     def __init__(self, status, message):
         super().__init__(f"wfpt status {status}: {message}")
@@ -106,6 +109,8 @@ def lib():
         "wfpt_scene_book_one_final": (u32, [C.c_uint64, vp, vp, u32]),
         "wfpt_build_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32)]),
         "wfpt_build_bvh_triangles": (i32, [vp, u32, vp, u32, C.POINTER(u32), u32]),
+        "wfpt_build_bvh_device": (i32, [vp, u32, vp, u32, C.POINTER(u32), i32, C.POINTER(f32)]),
+        "wfpt_build_bvh_triangles_device": (i32, [vp, u32, vp, u32, C.POINTER(u32), u32, i32, C.POINTER(f32)]),
         "wfpt_scene_random_mesh": (u32, [C.c_uint64, u32, vp, vp]),
         "wfpt_create_mesh": (vp, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]),
         "wfpt_camera_new": (None, [vp, vp, C.POINTER(f32), C.POINTER(f32)]),
@@ -252,26 +257,37 @@ class BVHTree:
         self.capacity = 2 * max(int(num_primitives), 1)
         self.nodes = np.zeros(0, BVH_NODE)
 
-    def build_bvh_tree(self, spheres):
+    def build_bvh_tree(self, spheres, device=None):
         """Reorders `spheres` (a SPHERE array) in place, like the reference."""
         if not (isinstance(spheres, np.ndarray) and spheres.dtype == SPHERE and spheres.flags.c_contiguous):
             raise TypeError("spheres must be a contiguous SPHERE array (it is reordered in place)")
         nodes = np.zeros(self.capacity, BVH_NODE)
         n = C.c_uint32()
-        st = lib().wfpt_build_bvh(_p(spheres), len(spheres), _p(nodes), len(nodes), C.byref(n))
+        if device is None:
+            st = lib().wfpt_build_bvh(_p(spheres), len(spheres), _p(nodes), len(nodes), C.byref(n))
+        else:  # build extension: the same builder on HIP device `device`, same bytes out
+            ms = C.c_float()
+            st = lib().wfpt_build_bvh_device(_p(spheres), len(spheres), _p(nodes), len(nodes), C.byref(n), device, C.byref(ms))
+            self.device_ms = ms.value
         if st != 0:
-            raise WfptError(st, "wfpt_build_bvh failed")
+            raise WfptError(st, "wfpt_build_bvh failed: " + lib().wfpt_last_error(None).decode())
         self.nodes = nodes[:n.value].copy()
 
-    def build_bvh_tree_triangles(self, triangles, n_bins=32):
+    def build_bvh_tree_triangles(self, triangles, n_bins=32, device=None):
         """Build extension: the same builder over a TRIANGLE array (reordered in place), n_bins bins per axis."""
         if not (isinstance(triangles, np.ndarray) and triangles.dtype == TRIANGLE and triangles.flags.c_contiguous):
             raise TypeError("triangles must be a contiguous TRIANGLE array (it is reordered in place)")
         nodes = np.zeros(self.capacity, BVH_NODE)
         n = C.c_uint32()
-        st = lib().wfpt_build_bvh_triangles(_p(triangles), len(triangles), _p(nodes), len(nodes), C.byref(n), n_bins)
+        if device is None:
+            st = lib().wfpt_build_bvh_triangles(_p(triangles), len(triangles), _p(nodes), len(nodes), C.byref(n), n_bins)
+        else:
+            ms = C.c_float()
+            st = lib().wfpt_build_bvh_triangles_device(_p(triangles), len(triangles), _p(nodes), len(nodes), C.byref(n), n_bins,
+                                                       device, C.byref(ms))
+            self.device_ms = ms.value
         if st != 0:
-            raise WfptError(st, "wfpt_build_bvh_triangles failed")
+            raise WfptError(st, "wfpt_build_bvh_triangles failed: " + lib().wfpt_last_error(None).decode())
         self.nodes = nodes[:n.value].copy()
 
 
@@ -490,7 +506,7 @@ class PathTracer:
     counter read-backs; `render(spp)` is the same loop resident on the device (no host synchronisation)."""
 
     def __init__(self, scene, rp, max_window_size=0, max_wavefronts=50, miss_floor=128, rng_mode=RNG_DISPATCH,
-                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0, mesh_bins=32):
+                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0, mesh_bins=32, device_bvh=False):
         L = lib()
         self.handle = None
         self.scene = scene
@@ -500,10 +516,10 @@ class PathTracer:
         self.max_wavefronts, self.miss_floor = max_wavefronts, miss_floor
         if scene.triangles is not None:
             bvh = BVHTree(len(scene.triangles))
-            bvh.build_bvh_tree_triangles(scene.triangles, mesh_bins)
+            bvh.build_bvh_tree_triangles(scene.triangles, mesh_bins, device=device if device_bvh else None)
         else:
             bvh = BVHTree(len(scene.spheres))
-            bvh.build_bvh_tree(scene.spheres)  # path_tracer.rs:117-118
+            bvh.build_bvh_tree(scene.spheres, device=device if device_bvh else None)  # path_tracer.rs:117-118
         self.bvh_tree = bvh
         cc = rp.camera_controller()
         w, h = rp.viewport_size()

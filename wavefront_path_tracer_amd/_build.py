@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwfpt.so")
-SOURCES = ["wfpt_kernels.hip", "wfpt_api.hip", "wfpt_host.cpp"]
+SOURCES = ["wfpt_kernels.hip", "wfpt_api.hip", "wfpt_bvh_build.hip", "wfpt_host.cpp"]
 HEADERS = [os.path.join(CSRC, "wfpt_kernels.h"), os.path.join(CSRC, "wfpt_device_math.h"),
            os.path.join(ROOT, "include", "wfpt.h")]
 # -ffp-contract=off: results must be bit-identical to the oracle, the only fused ops are explicit fmaf.

@@ -26,6 +26,10 @@ struct StageTimer {
 };
 } // namespace
 
+namespace wfpt {
+void set_last_error(const std::string &msg) { g_last_error = msg; } // for entry points without a context (wfpt_bvh_build.hip)
+} // namespace wfpt
+
 struct wfpt_ctx {
     wfpt_params p{};
     int device = 0;
