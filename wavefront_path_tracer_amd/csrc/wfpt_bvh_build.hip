@@ -317,7 +317,9 @@ __global__ __launch_bounds__(kBuildThreads) void split_kernel(BuildArgs A) {
     uint32_t best_axis = 0;
     float extent[3];
     for (int ax = 0; ax < 3; ++ax) extent[ax] = dec_hi(nd.hi[ax]) - dec_lo(nd.lo[ax]);
-    for (int ax = 0; ax < 3; ++ax) {
+    // a single primitive never splits (see small_subtree_kernel): no sweep
+    const bool lone = nd.count == 1u && isfinite(extent[0]) && isfinite(extent[1]) && isfinite(extent[2]);
+    for (int ax = 0; ax < 3 && !lone; ++ax) {
         if (extent[ax] < 0.00001f) continue; // workgroup-uniform
         const uint32_t *bins = A.bins + (static_cast<size_t>(a) * 3 + ax) * 7 * nb;
         // per-thread segment, then inclusive prefix and suffix scans over the threads
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(kBuildThreads) void split_kernel(BuildArgs A) {
         Decision d;
         d.plane = best_plane;
         d.axis = best_axis;
-        d.partition = (leaf_cost <= best_cost) ? 0u : 1u; // bvh.rs:172-174
+        d.partition = (lone || leaf_cost <= best_cost) ? 0u : 1u; // bvh.rs:172-174
         d.n_left = 0;
         d.split = 0;
         d.child = 0;
@@ -636,42 +638,61 @@ __global__ __launch_bounds__(64) void small_subtree_kernel(BuildArgs A, uint32_t
         box[3 + k] = dec_hi(root.hi[k]);
     }
     uint32_t sp = 0, n_pairs = 0;
+    uint32_t seg = 2; // bins per axis rounded up to a power of two (<= 64)
+    while (seg < nb) seg <<= 1;
+    const uint32_t per_pass = min(3u, 64u / seg);
     for (;;) {
-        // ---- find_best_split_plane, bvh.rs:73-139
+        // ---- find_best_split_plane, bvh.rs:73-139. The 64 lanes hold `per_pass` axes of `seg` bins each (seg = bin
+        // count rounded up to a power of two), so 32 bins take two passes instead of three; scans never cross a
+        // segment, and lane order = (axis, plane) order, which is the order the reference breaks cost ties in.
         float best_cost = __builtin_inff(), best_plane = 0.0f;
         uint32_t best_axis = 0;
-        const float extent[3] = {box[3] - box[0], box[4] - box[1], box[5] - box[2]};
+        const float ex = box[3] - box[0], ey = box[4] - box[1], ez = box[5] - box[2];
         const uint32_t slot = lane < count ? s_perm[first + lane] : 0u;
-        for (int ax = 0; ax < 3; ++ax) {
-            if (extent[ax] < 0.00001f) continue; // wave-uniform
-            for (int k = 0; k < 7; ++k) s_bins[k][lane] = 0; // kWaveBins == 64 lanes
+        // A single primitive never splits: every plane costs exactly 1 * area(its box), which is also the leaf
+        // cost, and bvh.rs:172 keeps the leaf on `<=` (finite extents keep NaN out of that comparison). Half of
+        // all nodes are such leaves, so they skip the sweep.
+        const bool lone = count == 1u && isfinite(ex) && isfinite(ey) && isfinite(ez);
+        uint32_t axes = 0, n_axes = 0; // wide axes, two bits each, in increasing order (bvh.rs:83-85 skips the narrow ones)
+        if (!(ex < 0.00001f)) { axes |= 0u << (2u * n_axes); n_axes += 1; }
+        if (!(ey < 0.00001f)) { axes |= 1u << (2u * n_axes); n_axes += 1; }
+        if (!(ez < 0.00001f)) { axes |= 2u << (2u * n_axes); n_axes += 1; }
+        const uint32_t bin = lane & (seg - 1u), group = lane / seg;
+        for (uint32_t g0 = 0; g0 < n_axes && !lone; g0 += per_pass) { // wave-uniform
+            const uint32_t in_pass = min(per_pass, n_axes - g0);
+            for (int k = 0; k < 7; ++k) s_bins[k][lane] = 0;
             __syncthreads();
             if (lane < count) {
-                const float scale = static_cast<float>(nb) / extent[ax];
-                const uint32_t b = static_cast<uint32_t>(bin_of(s_key[ax][slot], box[ax], scale, nb));
-                atomicAdd(&s_bins[0][b], 1u);
-                for (int k = 0; k < 3; ++k) {
-                    atomicMax(&s_bins[1 + k][b], enc_lo(s_lo[k][slot]));
-                    atomicMax(&s_bins[4 + k][b], enc_hi(s_hi[k][slot]));
+                for (uint32_t j = 0; j < in_pass; ++j) {
+                    const uint32_t ax = (axes >> (2u * (g0 + j))) & 3u;
+                    const float extent = ax == 0 ? ex : (ax == 1 ? ey : ez);
+                    const float lo_bound = ax == 0 ? box[0] : (ax == 1 ? box[1] : box[2]);
+                    const float scale = static_cast<float>(nb) / extent;
+                    const uint32_t b = j * seg + static_cast<uint32_t>(bin_of(s_key[ax][slot], lo_bound, scale, nb));
+                    atomicAdd(&s_bins[0][b], 1u);
+                    for (int k = 0; k < 3; ++k) {
+                        atomicMax(&s_bins[1 + k][b], enc_lo(s_lo[k][slot]));
+                        atomicMax(&s_bins[4 + k][b], enc_hi(s_hi[k][slot]));
+                    }
                 }
             }
             __syncthreads();
-            SweepBox mine; // lane = bin; lanes >= nb hold empty bins
+            SweepBox mine; // lane = (axis slot, bin); bins >= nb and unused slots are empty
             mine.n = s_bins[0][lane];
             mine.lx = dec_lo(s_bins[1][lane]); mine.ly = dec_lo(s_bins[2][lane]); mine.lz = dec_lo(s_bins[3][lane]);
             mine.hx = dec_hi(s_bins[4][lane]); mine.hy = dec_hi(s_bins[5][lane]); mine.hz = dec_hi(s_bins[6][lane]);
-            SweepBox left = mine, right = mine; // inclusive prefix / suffix over lanes
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) {
+            SweepBox left = mine, right = mine; // inclusive prefix / suffix inside the segment
+            for (uint32_t d = 1; d < seg; d <<= 1) {
                 const SweepBox pl = shfl_box_up(left, d), pr = shfl_box_down(right, d);
-                if (lane >= d) left.grow(pl);
-                if (lane + d < 64) right.grow(pr);
+                if (bin >= d) left.grow(pl);
+                if (bin + d < seg) right.grow(pr);
             }
-            const SweepBox beyond = shfl_box_down(right, 1); // bins lane+1 .. : right of plane `lane`
+            const SweepBox beyond = shfl_box_down(right, 1); // bins bin+1 .. of the same axis: right of plane `bin`
+            const bool plane_here = bin + 1u < nb && group < in_pass;
             float cost = __builtin_inff();
-            if (lane + 1 < nb) cost = static_cast<float>(left.n) * left.area() + static_cast<float>(beyond.n) * beyond.area();
-            // first strict minimum in plane order; NaN and +inf never win (bvh.rs:127)
-            bool cand = (lane + 1 < nb) && (cost < best_cost);
+            if (plane_here) cost = static_cast<float>(left.n) * left.area() + static_cast<float>(beyond.n) * beyond.area();
+            // first strict minimum in (axis, plane) order; NaN and +inf never win (bvh.rs:127)
+            const bool cand = plane_here && (cost < best_cost);
             float c = cand ? cost : __builtin_inff();
             uint32_t ci = cand ? lane : 0xffffffffu;
 #pragma unroll
@@ -684,18 +705,21 @@ __global__ __launch_bounds__(64) void small_subtree_kernel(BuildArgs A, uint32_t
                 }
             }
             if (ci != 0xffffffffu) {
+                const uint32_t ax = (axes >> (2u * (g0 + ci / seg))) & 3u;
+                const float extent = ax == 0 ? ex : (ax == 1 ? ey : ez);
+                const float lo_bound = ax == 0 ? box[0] : (ax == 1 ? box[1] : box[2]);
                 best_cost = c;
-                best_axis = static_cast<uint32_t>(ax);
+                best_axis = ax;
                 const float step = 1.0f / static_cast<float>(nb);
-                best_plane = box[ax] + extent[ax] * step * (1.0f + static_cast<float>(ci));
+                best_plane = lo_bound + extent * step * (1.0f + static_cast<float>(ci & (seg - 1u))); // bvh.rs:130
             }
             __syncthreads();
         }
         // ---- subdivide, bvh.rs:166-210
-        const float leaf_cost = static_cast<float>(count) * ((extent[0] * extent[1] + extent[1] * extent[2]) + extent[2] * extent[0]);
+        const float leaf_cost = static_cast<float>(count) * ((ex * ey + ey * ez) + ez * ex);
         bool split = false;
         uint32_t n_left = 0;
-        if (!(leaf_cost <= best_cost)) {
+        if (!lone && !(leaf_cost <= best_cost)) {
             const bool valid = lane < count;
             const bool is_left = valid && s_key[best_axis][slot] < best_plane;
             const unsigned long long left_mask = __ballot(is_left);
