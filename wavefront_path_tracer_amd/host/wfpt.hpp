@@ -58,12 +58,25 @@ struct Scene {
 struct BVHTree {
     std::vector<wfpt_bvh_node> nodes;
     explicit BVHTree(size_t num_primitives) { nodes.reserve(2 * num_primitives); }
-    void build_bvh_tree(std::vector<wfpt_sphere> &spheres) { // reorders spheres in place (bvh.rs:182)
+    float device_ms = 0.0f; // device builds: time between the first and the last build kernel
+    // Reorders spheres in place (bvh.rs:182). device < 0: the host builder; otherwise the same builder on that HIP
+    // device (build extension, wfpt_build_bvh_device) -- same nodes, same order, byte for byte.
+    void build_bvh_tree(std::vector<wfpt_sphere> &spheres, int device = -1) {
         nodes.assign(2 * (spheres.empty() ? 1 : spheres.size()), wfpt_bvh_node{});
         uint32_t n = 0;
-        const int st = wfpt_build_bvh(spheres.data(), static_cast<uint32_t>(spheres.size()), nodes.data(),
-                                      static_cast<uint32_t>(nodes.size()), &n);
-        if (st != WFPT_OK) throw Error(st, "wfpt_build_bvh");
+        const uint32_t count = static_cast<uint32_t>(spheres.size()), cap = static_cast<uint32_t>(nodes.size());
+        const int st = device < 0 ? wfpt_build_bvh(spheres.data(), count, nodes.data(), cap, &n)
+                                  : wfpt_build_bvh_device(spheres.data(), count, nodes.data(), cap, &n, device, &device_ms);
+        if (st != WFPT_OK) throw Error(st, std::string("wfpt_build_bvh: ") + wfpt_last_error(nullptr));
+        nodes.resize(n);
+    }
+    void build_bvh_tree_triangles(std::vector<wfpt_triangle> &triangles, uint32_t n_bins = 32, int device = -1) {
+        nodes.assign(2 * (triangles.empty() ? 1 : triangles.size()), wfpt_bvh_node{});
+        uint32_t n = 0;
+        const uint32_t count = static_cast<uint32_t>(triangles.size()), cap = static_cast<uint32_t>(nodes.size());
+        const int st = device < 0 ? wfpt_build_bvh_triangles(triangles.data(), count, nodes.data(), cap, &n, n_bins)
+                                  : wfpt_build_bvh_triangles_device(triangles.data(), count, nodes.data(), cap, &n, n_bins, device, &device_ms);
+        if (st != WFPT_OK) throw Error(st, std::string("wfpt_build_bvh_triangles: ") + wfpt_last_error(nullptr));
         nodes.resize(n);
     }
 };
