@@ -51,9 +51,10 @@ def test_mesh_stage_by_stage(gpu, orc, n_tris, scale, rng_mode):
 
 
 @pytest.mark.parametrize("n_tris,scale", MESHES)
-def test_mesh_device_loop(gpu, orc, n_tris, scale):
+@pytest.mark.parametrize("w,h", [(200, 120), (203, 125)])  # the second size leaves inactive padding rays in the queue
+def test_mesh_device_loop(gpu, orc, n_tris, scale, w, h):
     W = gpu
-    w, h, spp, bounces = 200, 120, 5, 6
+    spp, bounces = 5, 6
     o = make_mesh_oracle(orc, mesh_inputs(orc, w, h, n_tris, scale), w, h, max_wavefronts=bounces)
     want = o.render(spp)
     for batch in (1, 4):
@@ -76,3 +77,14 @@ def test_golden_mesh_on_gpu(gpu):
         assert_bit_equal(pt.accumulated(), g["acc"], "golden mesh image")
         assert np.array_equal(pt.bounce_table(), g["table"])
         pt.close()
+
+
+def test_hbm_mesh_per_material_split(gpu):
+    """Per-material hit lists (WFPT_FLAG_SPLIT_SHADE) written by the HBM-scene extend give the unsplit image."""
+    W = gpu
+    a = make_mesh_tracer(W, 320, 200, 30000, 6.0, max_wavefronts=5)
+    b = make_mesh_tracer(W, 320, 200, 30000, 6.0, max_wavefronts=5, flags=W.FLAG_SPLIT_SHADE)
+    a.render(3); b.render(3)
+    assert np.array_equal(a.bounce_table(), b.bounce_table())
+    assert_bit_equal(a.accumulated(), b.accumulated(), "split vs unified shade on an HBM-resident mesh")
+    a.close(); b.close()
