@@ -196,6 +196,13 @@ def test_tile_sharding_pixel_mode(gpu, orc):
             slabs.append(pt.accumulated())
             pt.close()
         assert_bit_equal(tiles.assemble(slabs, w, h), ref, f"assembled from {world} ranks")
+    # image chunking on one GPU (README.md:20): the same cut, rendered slab after slab with queues 1/5 the size
+    def chunk(rank, world):
+        return make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world)
+    probe = chunk(0, 5)
+    assert probe.ray_capacity < full.ray_capacity / 4
+    probe.close()
+    assert_bit_equal(tiles.render_in_chunks(chunk, w, h, spp, 5), ref, "rendered in 5 chunks")
     full.close()
 
 

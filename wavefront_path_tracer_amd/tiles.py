@@ -6,6 +6,9 @@ round-robin and the ranks stay balanced. Every rank runs the whole kernel chain 
 GLOBAL pixel coordinates (so generate_rays is bit-identical to a single-GPU render) and keeps its pixels in
 a compact slab of whole bands. There is no exchange inside the bounce loop; the only collective is one
 gather of the accumulated slabs at the end (RCCL over xGMI when the backend is "nccl").
+
+The same cut serves the reference's to-do "image chunking" (README.md:20) on ONE GPU:
+`render_in_chunks` renders the slabs one after the other, so the ray queues are sized for 1/chunks of the frame.
 """
 import numpy as np
 
@@ -83,4 +86,22 @@ def gather_slabs(local_slab, rank, world, width, height, device=None, group=None
     if keep_on_device:
         return assemble_torch(recv, width, height)
     slabs = [recv[r][:3 * slab_pixels(r, world, width, height)].cpu().numpy().reshape(-1, 3) for r in range(world)]
+    return assemble(slabs, width, height)
+
+
+def render_in_chunks(make_tracer, width, height, spp, chunks):
+    """Image chunking on one GPU: the frame is rendered as `chunks` band-interleaved slabs in sequence and
+    assembled, so every queue and image buffer on the device is sized for ceil(bands / chunks) bands instead of
+    the whole frame. `make_tracer(tile_rank, tile_world)` must return a PathTracer created with those two
+    parameters and rng_mode = RNG_PIXEL (the dispatch-keyed RNG of shade.wgsl:72 depends on the queue a ray sits
+    in, so only the pixel-keyed mode is independent of the cut). Returns the accumulated (width*height, 3) image,
+    bit-identical to the unchunked RNG_PIXEL render."""
+    slabs = []
+    for k in range(chunks):
+        pt = make_tracer(k, chunks)
+        try:
+            pt.render(spp)
+            slabs.append(pt.accumulated())
+        finally:
+            pt.close()
     return assemble(slabs, width, height)
