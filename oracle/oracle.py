@@ -93,6 +93,7 @@ def lib(serial=False):
     L.orc_create_mesh.restype = vp
     L.orc_create_mesh.argtypes = [C.POINTER(Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]
     L.orc_ray_steps.argtypes = [vp, u32, vp, vp]
+    L.orc_write_rays.argtypes = [vp, vp, u32]
     L.orc_camera_new.argtypes = [vp, vp, C.POINTER(f32), C.POINTER(f32)]
     L.orc_view_transform.argtypes = [vp, f32, f32, vp]
     L.orc_p_inv.argtypes = [f32, f32, f32, f32, vp]
@@ -266,6 +267,10 @@ class Oracle:
 
     def swap_ray_queues(self):
         self.L.orc_swap_ray_queues(self.h)
+
+    def write_rays(self, rays):
+        a = np.ascontiguousarray(rays, RAY)
+        self.L.orc_write_rays(self.h, _p(a), len(a))
 
     def generate_rays(self, gx, gy, true_size=False):
         self.L.orc_generate_rays(self.h, gx, gy, int(true_size))

@@ -569,6 +569,13 @@ void orc_reset_image(orc_ctx *c) { for (size_t i = 0; i < 3 * (size_t)c->n_pixel
 void orc_reset_accumulated(orc_ctx *c) { memset(c->accumulated, 0, sizeof(float) * 3 * c->n_pixels); }
 /* wgpu_state.rs:115-130: clear dst, copy src -> dst, clear src. Queues are count-guarded, so a swap is
  * equivalent; the clear of the source is kept so stale slots read as zero rays like in the reference. */
+/* Test hook (the product's wfpt_write_rays): overwrite the first n entries of the ray queue with caller-made rays,
+ * e.g. axis-parallel, zero-length or non-finite ones that generate_rays never produces. */
+void orc_write_rays(orc_ctx *c, const orc_ray *rays, uint32_t n) {
+    if (n > c->n_slots) n = c->n_slots;
+    memcpy(c->rays, rays, sizeof(orc_ray) * n);
+}
+
 void orc_swap_ray_queues(orc_ctx *c) {
     orc_ray *t = c->rays;
     c->rays = c->ext_rays;

@@ -107,6 +107,7 @@ void     orc_get_counters(const orc_ctx *, uint32_t c[16]);
 void     orc_reset_image(orc_ctx *);       /* path_tracer.rs:305-306 */
 void     orc_reset_accumulated(orc_ctx *); /* path_tracer.rs:248-250 */
 void     orc_swap_ray_queues(orc_ctx *);   /* path_tracer.rs:348 (wgpu_state.rs:115-130) */
+void     orc_write_rays(orc_ctx *, const orc_ray *rays, uint32_t n); /* test hook: caller-made rays into the ray queue */
 
 /* Stage kernels with the reference's dispatch semantics (gx*gy workgroups of 8x8). */
 void orc_generate_rays(orc_ctx *, uint32_t gx, uint32_t gy, int true_size);

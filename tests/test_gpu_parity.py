@@ -382,6 +382,63 @@ def test_single_sphere_root_leaf(gpu, orc):
     pt.close(); o.close()
 
 
+def _odd_rays(W, n, seed):
+    """Rays generate_rays never makes: axis-parallel (1/0 = inf in the slab test), zero-length, huge / tiny / denormal
+    magnitudes, origins inside spheres and exactly on box planes, NaN and infinite components."""
+    rng = np.random.default_rng(seed)
+    r = np.zeros(n, W.RAY)
+    r["origin"][:, :3] = rng.uniform(-12, 12, (n, 3)).astype("<f4")
+    r["origin"][:, 1] = np.abs(r["origin"][:, 1]) * np.float32(0.2)
+    r["origin"][:, 3] = 1.0
+    d = rng.normal(size=(n, 3)).astype("<f4")
+    kind = np.arange(n) % 16
+    d[kind == 1, 0] = 0.0                                  # parallel to the yz plane
+    d[kind == 2, 1:] = 0.0                                 # along x
+    d[kind == 3] = 0.0                                     # no direction at all
+    d[kind == 4] *= np.float32(1e-30)                      # inverse overflows for some
+    d[kind == 5] *= np.float32(1e-42)                      # denormal direction
+    d[kind == 6] *= np.float32(1e18)                       # a = d.d overflows
+    d[kind == 7, 2] = np.float32(-0.0)
+    r["origin"][kind == 8, :3] = np.float32([4.0, 1.0, 0.0])   # centre of a big sphere (scene.rs:97-99)
+    r["origin"][kind == 9, :3] = np.float32([0.0, -1000.0, 0.0])  # centre of the ground sphere
+    d[kind == 10, 0] = np.float32(np.nan)
+    r["origin"][kind == 11, 2] = np.float32(np.inf)
+    d[kind == 12, 1] = np.float32(-np.inf)
+    r["origin"][kind == 13, 1] = np.float32(0.0)           # on the ground: t ~ 0 roots against the 0.001 window
+    d[kind == 13, 1] = -np.abs(d[kind == 13, 1])
+    r["origin"][kind == 14, :3] = np.float32(1e30)
+    r["direction"][:, :3] = d
+    with np.errstate(all="ignore"):
+        r["inv_direction"] = (np.float32(1.0) / d).astype("<f4")  # carried by the reference's Ray, recomputed by extend
+    r["pixel_idx"] = np.arange(n, dtype="<u4") % 1000
+    return r
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_extend_on_degenerate_rays(gpu, orc, seed):
+    """extend on hand-made rays full of zeros, infinities, NaNs and denormals: the slab test's min/max chain, the
+    quadratic's sqrt and divide and the (0.001, nearest) window must treat them like the oracle does, bit for bit."""
+    W = gpu
+    w, h = 128, 64
+    n = w * h
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h)
+    pt = make_tracer(W, "shirley", w, h)
+    rays = _odd_rays(W, n, seed)
+    pt.set_frame(W.GPUFrameBuffer.new(w, h, 1)); o.set_frame(1, 0)
+    pt.write_rays(rays); o.write_rays(rays.view(orc.RAY))
+    assert_bit_equal(pt.rays(n), o.rays(n).view(W.RAY), "injected rays")
+    pt.set_counters([0, 0, n]); o.set_counters([0, 0, n])
+    ext = W.workgroup_size_64(n)
+    pt.extend_kernel.run(ext); o.extend(*ext)
+    c = o.counters()
+    assert np.array_equal(pt.read_counters()[:3], c[:3])
+    misses, hits = int(c[0]), int(c[1])
+    assert hits > n // 8 and misses > n // 8
+    assert_bit_equal(pt.hits(hits), o.hits(hits).view(W.HIT), "hit queue of the degenerate rays")
+    assert_bit_equal(pt.misses(misses), o.misses(misses), "miss queue of the degenerate rays")
+    pt.close(); o.close()
+
+
 @pytest.mark.parametrize("max_wavefronts,miss_floor", [(1, 128), (3, 0), (50, 10 ** 9), (50, 128), (64, 1)])
 def test_loop_termination_policies(gpu, orc, max_wavefronts, miss_floor):
     """path_tracer.rs:323,332: `wavefront < max` and `misses < miss_floor -> break` evaluated on the device.
