@@ -70,7 +70,8 @@ struct BuildCtl {
     uint32_t n_nodes;    // provisional nodes allocated
     uint32_t n_next;     // nodes queued for the next level
     uint32_t n_small;    // wave-built subtree roots queued
-    uint32_t n_chunks;   // chunks of the current level
+    uint32_t n_chunks;   // chunks of the level that was set up last
+    uint32_t n_active;   // ... and its node count
     uint32_t sub_alloc;  // subtree node records allocated
     uint32_t overflow;   // a capacity was exceeded (nothing was written out of bounds)
 };
@@ -195,16 +196,20 @@ __global__ __launch_bounds__(kBuildThreads) void prep_prims_kernel(const void *p
 
 // ---------------------------------------------------------------------------------------------- level set-up
 // One workgroup: cut every active node into chunks of kBuildChunk primitives.
-__global__ __launch_bounds__(kBuildThreads) void setup_level_kernel(BuildArgs A) {
+// `from_queue`: the level is the one the previous level's offsets_kernel has just queued (count in ctl->n_next), so a
+// level costs one host round trip (reading back n_active / n_chunks for the launch sizes) instead of two.
+__global__ __launch_bounds__(kBuildThreads) void setup_level_kernel(BuildArgs A, uint32_t from_queue) {
     __shared__ uint32_t s_scan[kBuildThreads / 64];
+    const uint32_t n_active = from_queue ? A.ctl->n_next : A.n_active;
+    __syncthreads(); // everyone has read n_next before thread 0 resets it below
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < A.n_active; base += kBuildThreads) {
+    for (uint32_t base = 0; base < n_active; base += kBuildThreads) {
         const uint32_t a = base + threadIdx.x;
-        const uint32_t count = a < A.n_active ? A.nodes[A.active[a]].count : 0u;
+        const uint32_t count = a < n_active ? A.nodes[A.active[a]].count : 0u;
         const uint32_t chunks = (count + kBuildChunk - 1) / kBuildChunk;
         uint32_t total;
         const uint32_t first = carry + block_scan_excl(chunks, s_scan, total);
-        if (a < A.n_active) {
+        if (a < n_active) {
             A.chunk_first[a] = first;
             for (uint32_t k = 0; k < chunks && first + k < A.chunk_cap; ++k) {
                 A.chunk_node[first + k] = a;
@@ -214,8 +219,9 @@ __global__ __launch_bounds__(kBuildThreads) void setup_level_kernel(BuildArgs A)
         carry += total;
     }
     if (threadIdx.x == 0) {
-        A.chunk_first[A.n_active] = carry;
+        A.chunk_first[n_active] = carry;
         A.ctl->n_chunks = carry;
+        A.ctl->n_active = n_active;
         if (carry > A.chunk_cap) A.ctl->overflow = 1;
         A.ctl->n_next = 0;
     }
@@ -449,24 +455,18 @@ __global__ __launch_bounds__(kBuildThreads) void classify_kernel(BuildArgs A) {
     if (threadIdx.x == 0) A.chunk_left[c] = total;
 }
 
-// Per node: prefix of its chunks' left counts, the split decision, the children (bvh.rs:188-209).
+// Per node (one thread each): prefix of its chunks' left counts, the split decision, the children (bvh.rs:188-209).
 __global__ __launch_bounds__(kBuildThreads) void offsets_kernel(BuildArgs A) {
-    __shared__ uint32_t s_scan[kBuildThreads / 64];
-    const uint32_t a = blockIdx.x;
+    const uint32_t a = blockIdx.x * kBuildThreads + threadIdx.x;
+    if (a >= A.n_active) return;
     Decision d = A.dec[a];
     if (!d.partition) return;
     const uint32_t self = A.active[a];
-    const uint32_t c0 = A.chunk_first[a], c1 = A.chunk_first[a + 1];
     uint32_t carry = 0;
-    for (uint32_t base = c0; base < c1; base += kBuildThreads) {
-        const uint32_t c = base + threadIdx.x;
-        const uint32_t v = c < c1 ? A.chunk_left[c] : 0u;
-        uint32_t total;
-        const uint32_t before = carry + block_scan_excl(v, s_scan, total);
-        if (c < c1) A.chunk_left_before[c] = before;
-        carry += total;
+    for (uint32_t c = A.chunk_first[a]; c < A.chunk_first[a + 1]; ++c) {
+        A.chunk_left_before[c] = carry;
+        carry += A.chunk_left[c];
     }
-    if (threadIdx.x != 0) return;
     const BuildNode nd = A.nodes[self];
     d.n_left = carry;
     if (carry != 0 && carry != nd.count) { // bvh.rs:188-190
@@ -594,6 +594,91 @@ __device__ __forceinline__ SweepBox shfl_box_down(const SweepBox &b, uint32_t d)
     return o;
 }
 
+// The sweep of find_best_split_plane (bvh.rs:104-133) by one wave. Lane = (axis slot `group`, bin `bin`) holds that
+// bin (`mine`; empty for bins >= nb and unused slots); `seg` (a power of two) bins per slot, `in_pass` slots in use.
+// Returns the first strict minimum below `best_cost` in (slot, plane) order -- the order the reference breaks cost
+// ties in -- as (cost, lane), or lane 0xffffffff if no plane beats `best_cost`.
+__device__ __forceinline__ void wave_sweep(const SweepBox &mine, uint32_t bin, uint32_t group, uint32_t seg, uint32_t nb, uint32_t in_pass,
+                                           float best_cost, float &c, uint32_t &ci) {
+    const uint32_t lane = lane_id();
+    SweepBox left = mine, right = mine; // inclusive prefix / suffix inside the segment
+    for (uint32_t d = 1; d < seg; d <<= 1) {
+        const SweepBox pl = shfl_box_up(left, d), pr = shfl_box_down(right, d);
+        if (bin >= d) left.grow(pl);
+        if (bin + d < seg) right.grow(pr);
+    }
+    const SweepBox beyond = shfl_box_down(right, 1); // bins bin+1 .. of the same axis: right of plane `bin`
+    const bool plane_here = bin + 1u < nb && group < in_pass;
+    float cost = __builtin_inff();
+    if (plane_here) cost = static_cast<float>(left.n) * left.area() + static_cast<float>(beyond.n) * beyond.area();
+    // NaN and +inf never win (bvh.rs:127)
+    const bool cand = plane_here && (cost < best_cost);
+    c = cand ? cost : __builtin_inff();
+    ci = cand ? lane : 0xffffffffu;
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        const float oc = __shfl_xor(c, d);
+        const uint32_t oi = __shfl_xor(ci, d);
+        if (oc < c || (oc == c && oi < ci)) {
+            c = oc;
+            ci = oi;
+        }
+    }
+}
+
+// split_kernel for at most 64 bins: one WAVE per active node (four nodes per workgroup), bins straight from global memory
+// into lanes, no LDS, no barriers.
+__global__ __launch_bounds__(kBuildThreads) void split_wave_kernel(BuildArgs A) {
+    const uint32_t a = blockIdx.x * (kBuildThreads / 64) + (threadIdx.x >> 6);
+    if (a >= A.n_active) return; // wave-uniform
+    const uint32_t lane = lane_id(), nb = A.n_bins;
+    const BuildNode nd = A.nodes[A.active[a]];
+    const float lo[3] = {dec_lo(nd.lo[0]), dec_lo(nd.lo[1]), dec_lo(nd.lo[2])};
+    const float ex = dec_hi(nd.hi[0]) - lo[0], ey = dec_hi(nd.hi[1]) - lo[1], ez = dec_hi(nd.hi[2]) - lo[2];
+    uint32_t seg = 2;
+    while (seg < nb) seg <<= 1;
+    const uint32_t per_pass = min(3u, 64u / seg);
+    const uint32_t bin = lane & (seg - 1u), group = lane / seg;
+    uint32_t axes = 0, n_axes = 0; // wide axes, two bits each, in increasing order
+    if (!(ex < 0.00001f)) { axes |= 0u << (2u * n_axes); n_axes += 1; }
+    if (!(ey < 0.00001f)) { axes |= 1u << (2u * n_axes); n_axes += 1; }
+    if (!(ez < 0.00001f)) { axes |= 2u << (2u * n_axes); n_axes += 1; }
+    const bool lone = nd.count == 1u && isfinite(ex) && isfinite(ey) && isfinite(ez); // see small_subtree_kernel
+    float best_cost = __builtin_inff(), best_plane = 0.0f;
+    uint32_t best_axis = 0;
+    for (uint32_t g0 = 0; g0 < n_axes && !lone; g0 += per_pass) {
+        const uint32_t in_pass = min(per_pass, n_axes - g0);
+        SweepBox mine;
+        mine.clear();
+        if (group < in_pass && bin < nb) {
+            const uint32_t ax = (axes >> (2u * (g0 + group))) & 3u;
+            mine = load_bin(A.bins + (static_cast<size_t>(a) * 3 + ax) * 7 * nb, nb, bin);
+        }
+        float c;
+        uint32_t ci;
+        wave_sweep(mine, bin, group, seg, nb, in_pass, best_cost, c, ci);
+        if (ci != 0xffffffffu) {
+            const uint32_t ax = (axes >> (2u * (g0 + ci / seg))) & 3u;
+            const float extent = ax == 0 ? ex : (ax == 1 ? ey : ez);
+            best_cost = c;
+            best_axis = ax;
+            const float step = 1.0f / static_cast<float>(nb);
+            best_plane = (ax == 0 ? lo[0] : (ax == 1 ? lo[1] : lo[2])) + extent * step * (1.0f + static_cast<float>(ci & (seg - 1u))); // bvh.rs:130
+        }
+    }
+    if (lane == 0) {
+        const float leaf_cost = static_cast<float>(nd.count) * ((ex * ey + ey * ez) + ez * ex);
+        Decision d;
+        d.plane = best_plane;
+        d.axis = best_axis;
+        d.partition = (lone || leaf_cost <= best_cost) ? 0u : 1u; // bvh.rs:172-174
+        d.n_left = 0;
+        d.split = 0;
+        d.child = 0;
+        A.dec[a] = d;
+    }
+}
+
 __global__ __launch_bounds__(64) void small_subtree_kernel(BuildArgs A, uint32_t n_small) {
     __shared__ float s_key[3][64], s_lo[3][64], s_hi[3][64];
     __shared__ uint32_t s_id[64], s_perm[64];
@@ -681,29 +766,9 @@ __global__ __launch_bounds__(64) void small_subtree_kernel(BuildArgs A, uint32_t
             mine.n = s_bins[0][lane];
             mine.lx = dec_lo(s_bins[1][lane]); mine.ly = dec_lo(s_bins[2][lane]); mine.lz = dec_lo(s_bins[3][lane]);
             mine.hx = dec_hi(s_bins[4][lane]); mine.hy = dec_hi(s_bins[5][lane]); mine.hz = dec_hi(s_bins[6][lane]);
-            SweepBox left = mine, right = mine; // inclusive prefix / suffix inside the segment
-            for (uint32_t d = 1; d < seg; d <<= 1) {
-                const SweepBox pl = shfl_box_up(left, d), pr = shfl_box_down(right, d);
-                if (bin >= d) left.grow(pl);
-                if (bin + d < seg) right.grow(pr);
-            }
-            const SweepBox beyond = shfl_box_down(right, 1); // bins bin+1 .. of the same axis: right of plane `bin`
-            const bool plane_here = bin + 1u < nb && group < in_pass;
-            float cost = __builtin_inff();
-            if (plane_here) cost = static_cast<float>(left.n) * left.area() + static_cast<float>(beyond.n) * beyond.area();
-            // first strict minimum in (axis, plane) order; NaN and +inf never win (bvh.rs:127)
-            const bool cand = plane_here && (cost < best_cost);
-            float c = cand ? cost : __builtin_inff();
-            uint32_t ci = cand ? lane : 0xffffffffu;
-#pragma unroll
-            for (uint32_t d = 32; d > 0; d >>= 1) {
-                const float oc = __shfl_xor(c, d);
-                const uint32_t oi = __shfl_xor(ci, d);
-                if (oc < c || (oc == c && oi < ci)) {
-                    c = oc;
-                    ci = oi;
-                }
-            }
+            float c;
+            uint32_t ci;
+            wave_sweep(mine, bin, group, seg, nb, in_pass, best_cost, c, ci);
             if (ci != 0xffffffffu) {
                 const uint32_t ax = (axes >> (2u * (g0 + ci / seg))) & 3u;
                 const float extent = ax == 0 ? ex : (ax == 1 ? ey : ez);
@@ -957,36 +1022,42 @@ int build_on_device(Prim *prims, uint32_t n, wfpt_bvh_node *out_nodes, uint32_t 
                        soa + 6 * static_cast<size_t>(n), soa + 7 * static_cast<size_t>(n), soa + 8 * static_cast<size_t>(n), A.ids, A.nodes);
     BUILD_HIP(hipGetLastError());
 
-    // ---- large nodes, level by level
-    uint32_t n_active = root_small ? 0u : 1u;
+    // ---- large nodes, level by level; one host round trip per level (the launch sizes of the next one)
+    uint32_t n_active = root_small ? 0u : 1u, n_chunks = 0;
     int cur = 0;
     uint32_t levels = 0;
+    if (n_active) {
+        A.active = active[0];
+        A.n_active = 1;
+        hipLaunchKernelGGL(setup_level_kernel, dim3(1), dim3(kBuildThreads), 0, stream, A, 0u);
+        n_chunks = (n + kBuildChunk - 1) / kBuildChunk; // the root's chunks
+    }
     while (n_active > 0) {
         if (++levels > 4096) return fail_build(WFPT_ERR_UNSUPPORTED, "device BVH build: tree deeper than 4096 levels");
         A.active = active[cur];
         A.next_active = active[cur ^ 1];
         A.n_active = n_active;
-        hipLaunchKernelGGL(setup_level_kernel, dim3(1), dim3(kBuildThreads), 0, stream, A);
         BUILD_HIP(hipMemsetAsync(A.bins, 0, sizeof(uint32_t) * static_cast<size_t>(n_active) * 3 * 7 * n_bins, stream));
-        BuildCtl now{};
-        BUILD_HIP(hipMemcpyAsync(&now, A.ctl, sizeof now, hipMemcpyDeviceToHost, stream));
-        BUILD_HIP(hipStreamSynchronize(stream));
-        if (now.overflow || now.n_chunks == 0 || now.n_chunks > chunk_cap)
-            return fail_build(WFPT_ERR_HIP, "device BVH build: internal capacity exceeded while cutting a level into chunks");
-        const uint32_t n_chunks = now.n_chunks;
         hipLaunchKernelGGL(bin_kernel, dim3(n_chunks), dim3(kBuildThreads), 0, stream, A);
-        hipLaunchKernelGGL(split_kernel, dim3(n_active), dim3(kBuildThreads), 0, stream, A);
+        if (use_wave) hipLaunchKernelGGL(split_wave_kernel, dim3((n_active + 3u) / 4u), dim3(kBuildThreads), 0, stream, A);
+        else hipLaunchKernelGGL(split_kernel, dim3(n_active), dim3(kBuildThreads), 0, stream, A);
         hipLaunchKernelGGL(classify_kernel, dim3(n_chunks), dim3(kBuildThreads), 0, stream, A);
-        hipLaunchKernelGGL(offsets_kernel, dim3(n_active), dim3(kBuildThreads), 0, stream, A);
+        hipLaunchKernelGGL(offsets_kernel, dim3((n_active + kBuildThreads - 1) / kBuildThreads), dim3(kBuildThreads), 0, stream, A);
         hipLaunchKernelGGL(rank_kernel, dim3(n_chunks), dim3(kBuildThreads), 0, stream, A);
         hipLaunchKernelGGL(scatter_kernel, dim3(n_chunks), dim3(kBuildThreads), 0, stream, A);
         hipLaunchKernelGGL(copy_back_kernel, dim3(n_chunks), dim3(kBuildThreads), 0, stream, A);
+        BuildArgs next = A; // cut the level that offsets_kernel has just queued
+        next.active = active[cur ^ 1];
+        hipLaunchKernelGGL(setup_level_kernel, dim3(1), dim3(kBuildThreads), 0, stream, next, 1u);
         BUILD_HIP(hipGetLastError());
+        BuildCtl now{};
         BUILD_HIP(hipMemcpyAsync(&now, A.ctl, sizeof now, hipMemcpyDeviceToHost, stream));
         BUILD_HIP(hipStreamSynchronize(stream));
-        if (now.overflow || now.n_next > max_active || now.n_nodes > node_cap)
+        if (now.overflow || now.n_active > max_active || now.n_nodes > node_cap || now.n_chunks > chunk_cap ||
+            (now.n_active > 0 && now.n_chunks == 0))
             return fail_build(WFPT_ERR_HIP, "device BVH build: internal capacity exceeded while splitting a level");
-        n_active = now.n_next;
+        n_active = now.n_active;
+        n_chunks = now.n_chunks;
         cur ^= 1;
     }
     // ---- small subtrees
