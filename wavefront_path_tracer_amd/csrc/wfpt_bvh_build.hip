@@ -77,8 +77,10 @@ struct BuildCtl {
 };
 
 struct BuildArgs {
-    // primitives, indexed by primitive id
-    const float *key[3], *plo[3], *phi[3];
+    // per-primitive records in POSITION order (they move with the partition, so every pass streams them):
+    // bin key, box; `ids` = which input primitive sits at each position. `t_*`: the scatter's destination copy.
+    float *key[3], *plo[3], *phi[3];
+    float *t_key[3], *t_plo[3], *t_phi[3];
     uint32_t n, n_bins, use_wave;
     uint32_t *ids, *tmp;
     BuildNode *nodes;
@@ -252,15 +254,15 @@ __global__ __launch_bounds__(kBuildThreads) void bin_kernel(BuildArgs A) {
     }
     uint32_t *g_bins = A.bins + static_cast<size_t>(a) * 3 * 7 * nb;
     for (uint32_t i = threadIdx.x; i < cnt; i += kBuildThreads) {
-        const uint32_t id = A.ids[nd.first + off + i];
+        const uint32_t pos = nd.first + off + i;
         uint32_t elo[3], ehi[3];
         for (int k = 0; k < 3; ++k) {
-            elo[k] = enc_lo(A.plo[k][id]);
-            ehi[k] = enc_hi(A.phi[k][id]);
+            elo[k] = enc_lo(A.plo[k][pos]);
+            ehi[k] = enc_hi(A.phi[k][pos]);
         }
         for (int ax = 0; ax < 3; ++ax) {
             if (!wide[ax]) continue;
-            const uint32_t b = static_cast<uint32_t>(bin_of(A.key[ax][id], lo_bound[ax], scale[ax], nb));
+            const uint32_t b = static_cast<uint32_t>(bin_of(A.key[ax][pos], lo_bound[ax], scale[ax], nb));
             uint32_t *bins = (local ? s_bins : g_bins) + static_cast<size_t>(ax) * 7 * nb;
             atomicAdd(&bins[b], 1u);
             for (int k = 0; k < 3; ++k) {
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(kBuildThreads) void classify_kernel(BuildArgs A) {
     const uint32_t cnt = min(kBuildChunk, nd.count - off);
     uint32_t mine = 0;
     for (uint32_t i = threadIdx.x; i < cnt; i += kBuildThreads)
-        mine += A.key[d.axis][A.ids[nd.first + off + i]] < d.plane ? 1u : 0u; // bvh.rs:179
+        mine += A.key[d.axis][nd.first + off + i] < d.plane ? 1u : 0u; // bvh.rs:179
     uint32_t total;
     block_scan_excl(mine, s_scan, total);
     if (threadIdx.x == 0) A.chunk_left[c] = total;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(kBuildThreads) void offsets_kernel(BuildArgs A) {
     A.dec[a] = d;
 }
 
-// Walks one chunk in position order and hands every element (position in node, id, class, lefts before it) to f.
+// Walks one chunk in position order and hands every element (position in node, class, lefts before it) to f.
 template <typename F> __device__ __forceinline__ void for_each_classified(const BuildArgs &A, uint32_t c, const BuildNode &nd,
                                                                           const Decision &d, uint32_t *s_scan, F f) {
     const uint32_t off = A.chunk_off[c];
@@ -505,11 +507,10 @@ template <typename F> __device__ __forceinline__ void for_each_classified(const 
     for (uint32_t base = 0; base < cnt; base += kBuildThreads) { // workgroup-uniform trip count
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < cnt;
-        const uint32_t id = valid ? A.ids[nd.first + off + i] : 0u;
-        const bool is_left = valid && A.key[d.axis][id] < d.plane;
+        const bool is_left = valid && A.key[d.axis][nd.first + off + i] < d.plane;
         uint32_t total;
         const uint32_t before = carry + block_scan_excl(is_left ? 1u : 0u, s_scan, total);
-        if (valid) f(off + i, id, is_left, before);
+        if (valid) f(off + i, is_left, before);
         carry += total;
     }
 }
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(kBuildThreads) void rank_kernel(BuildArgs A) {
     if (!d.partition) return;
     const BuildNode nd = A.nodes[A.active[a]];
     uint32_t *head_r = A.head_r + nd.first, *tail_l = A.tail_l + nd.first;
-    for_each_classified(A, c, nd, d, s_scan, [&](uint32_t s, uint32_t, bool is_left, uint32_t left_before) {
+    for_each_classified(A, c, nd, d, s_scan, [&](uint32_t s, bool is_left, uint32_t left_before) {
         if (is_left) {
             if (s >= d.n_left) tail_l[d.n_left - left_before] = s;
         } else if (s <= d.n_left) {
@@ -542,14 +543,23 @@ __global__ __launch_bounds__(kBuildThreads) void scatter_kernel(BuildArgs A) {
     if (threadIdx.x < 12) s_box[threadIdx.x / 6][threadIdx.x % 6] = 0;
     __syncthreads();
     const uint32_t *head_r = A.head_r + nd.first, *tail_l = A.tail_l + nd.first;
-    for_each_classified(A, c, nd, d, s_scan, [&](uint32_t s, uint32_t id, bool is_left, uint32_t left_before) {
-        const uint32_t dest = partition_dest(is_left, s, left_before, d.n_left, nd.count, head_r, tail_l);
-        A.tmp[nd.first + dest] = id;
+    for_each_classified(A, c, nd, d, s_scan, [&](uint32_t s, bool is_left, uint32_t left_before) {
+        const uint32_t dest = nd.first + partition_dest(is_left, s, left_before, d.n_left, nd.count, head_r, tail_l);
+        const uint32_t src = nd.first + s;
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = A.plo[k][src];
+            hi[k] = A.phi[k][src];
+            A.t_plo[k][dest] = lo[k];
+            A.t_phi[k][dest] = hi[k];
+            A.t_key[k][dest] = A.key[k][src];
+        }
+        A.tmp[dest] = A.ids[src];
         if (d.split) { // update_node_bounds of the child it lands in, bvh.rs:196,202
-            const uint32_t side = dest < d.n_left ? 0u : 1u;
+            const uint32_t side = dest - nd.first < d.n_left ? 0u : 1u;
             for (int k = 0; k < 3; ++k) {
-                atomicMax(&s_box[side][k], enc_lo(A.plo[k][id]));
-                atomicMax(&s_box[side][3 + k], enc_hi(A.phi[k][id]));
+                atomicMax(&s_box[side][k], enc_lo(lo[k]));
+                atomicMax(&s_box[side][3 + k], enc_hi(hi[k]));
             }
         }
     });
@@ -568,7 +578,15 @@ __global__ __launch_bounds__(kBuildThreads) void copy_back_kernel(BuildArgs A) {
     const BuildNode nd = A.nodes[A.active[a]];
     const uint32_t off = A.chunk_off[c];
     const uint32_t cnt = min(kBuildChunk, nd.count - off);
-    for (uint32_t i = threadIdx.x; i < cnt; i += kBuildThreads) A.ids[nd.first + off + i] = A.tmp[nd.first + off + i];
+    for (uint32_t i = threadIdx.x; i < cnt; i += kBuildThreads) {
+        const uint32_t pos = nd.first + off + i;
+        A.ids[pos] = A.tmp[pos];
+        for (int k = 0; k < 3; ++k) {
+            A.key[k][pos] = A.t_key[k][pos];
+            A.plo[k][pos] = A.t_plo[k][pos];
+            A.phi[k][pos] = A.t_phi[k][pos];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- small subtrees
@@ -704,12 +722,12 @@ __global__ __launch_bounds__(64) void small_subtree_kernel(BuildArgs A, uint32_t
         return;
     }
     if (lane < n) {
-        const uint32_t id = A.ids[root.first + lane];
-        s_id[lane] = id;
+        const uint32_t pos = root.first + lane;
+        s_id[lane] = A.ids[pos];
         for (int k = 0; k < 3; ++k) {
-            s_key[k][lane] = A.key[k][id];
-            s_lo[k][lane] = A.plo[k][id];
-            s_hi[k][lane] = A.phi[k][id];
+            s_key[k][lane] = A.key[k][pos];
+            s_lo[k][lane] = A.plo[k][pos];
+            s_hi[k][lane] = A.phi[k][pos];
         }
     }
     s_perm[lane] = lane;
@@ -958,7 +976,7 @@ int build_on_device(Prim *prims, uint32_t n, wfpt_bvh_node *out_nodes, uint32_t 
     wfpt_bvh_node *d_out = nullptr;
     BUILD_HIP(mem.alloc(&d_prims, n));
     BUILD_HIP(mem.alloc(&d_sorted, n));
-    BUILD_HIP(mem.alloc(&soa, 9 * static_cast<size_t>(n)));
+    BUILD_HIP(mem.alloc(&soa, 18 * static_cast<size_t>(n)));
     BUILD_HIP(mem.alloc(&A.ids, n));
     BUILD_HIP(mem.alloc(&A.tmp, n));
     BUILD_HIP(mem.alloc(&A.nodes, node_cap));
@@ -984,6 +1002,9 @@ int build_on_device(Prim *prims, uint32_t n, wfpt_bvh_node *out_nodes, uint32_t 
         A.key[k] = soa + static_cast<size_t>(k) * n;
         A.plo[k] = soa + static_cast<size_t>(3 + k) * n;
         A.phi[k] = soa + static_cast<size_t>(6 + k) * n;
+        A.t_key[k] = soa + static_cast<size_t>(9 + k) * n;
+        A.t_plo[k] = soa + static_cast<size_t>(12 + k) * n;
+        A.t_phi[k] = soa + static_cast<size_t>(15 + k) * n;
     }
     A.n = n;
     A.n_bins = n_bins;
