@@ -31,6 +31,7 @@ constexpr uint32_t kBuildThreads = 256;
 constexpr uint32_t kBuildChunk = 1024; // primitives per workgroup pass
 constexpr uint32_t kSmallPrims = 64;   // subtrees of at most this many primitives are finished by one wave
 constexpr uint32_t kWaveBins = 64;     // ... when the bin count fits one wave
+constexpr uint32_t kDirectPrims = 8;   // inside such a subtree, nodes this small skip the bins (3 * 9 candidate lanes)
 constexpr uint32_t kMaxBins = 4096;    // bvh.rs:4
 
 // ---- order-preserving integer image of a float, so that min / max become integer atomics
@@ -761,7 +762,65 @@ __global__ __launch_bounds__(64) void small_subtree_kernel(BuildArgs A, uint32_t
         if (!(ey < 0.00001f)) { axes |= 1u << (2u * n_axes); n_axes += 1; }
         if (!(ez < 0.00001f)) { axes |= 2u << (2u * n_axes); n_axes += 1; }
         const uint32_t bin = lane & (seg - 1u), group = lane / seg;
-        for (uint32_t g0 = 0; g0 < n_axes && !lone; g0 += per_pass) { // wave-uniform
+        const bool direct = count <= kDirectPrims && !lone;
+        if (direct) {
+            // Few primitives: the cost only changes at planes where a primitive's bin ends, and the reference takes
+            // the first plane of each run of equal costs, so the candidates are plane 0 and the primitives' own bins:
+            // (count + 1) lanes per axis evaluate them straight from the primitives' boxes. Left of plane i = the
+            // primitives whose bin is <= i, exactly the bins the sweep would have merged; same cost expression.
+            if (lane < count) {
+                for (uint32_t j = 0; j < n_axes; ++j) {
+                    const uint32_t ax = (axes >> (2u * j)) & 3u;
+                    const float extent = ax == 0 ? ex : (ax == 1 ? ey : ez);
+                    const float lo_bound = ax == 0 ? box[0] : (ax == 1 ? box[1] : box[2]);
+                    s_bins[j][lane] = static_cast<uint32_t>(bin_of(s_key[ax][slot], lo_bound, static_cast<float>(nb) / extent, nb));
+                }
+            }
+            __syncthreads();
+            const uint32_t per_axis = count + 1u;
+            const uint32_t j = lane / per_axis, k = lane % per_axis; // axis slot, candidate
+            const bool in_range = j < n_axes;
+            const uint32_t plane = (in_range && k > 0u) ? s_bins[j][k - 1u] : 0u;
+            SweepBox left, right;
+            left.clear();
+            right.clear();
+            for (uint32_t p = 0; p < count; ++p) { // wave-uniform trip count
+                const uint32_t ps = s_perm[first + p];
+                SweepBox one;
+                one.lx = s_lo[0][ps]; one.ly = s_lo[1][ps]; one.lz = s_lo[2][ps];
+                one.hx = s_hi[0][ps]; one.hy = s_hi[1][ps]; one.hz = s_hi[2][ps];
+                one.n = 1;
+                const bool on_left = in_range && s_bins[j][p] <= plane;
+                SweepBox none;
+                none.clear();
+                left.grow(on_left ? one : none);
+                right.grow(on_left ? none : one);
+            }
+            const float cost = static_cast<float>(left.n) * left.area() + static_cast<float>(right.n) * right.area();
+            const bool cand = in_range && plane + 1u < nb && cost < best_cost; // NaN and +inf never win (bvh.rs:127)
+            float c = cand ? cost : __builtin_inff();
+            uint32_t ci = cand ? j * 64u + plane : 0xffffffffu; // (axis, plane) order; nb <= 64 here
+#pragma unroll
+            for (uint32_t d = 32; d > 0; d >>= 1) {
+                const float oc = __shfl_xor(c, d);
+                const uint32_t oi = __shfl_xor(ci, d);
+                if (oc < c || (oc == c && oi < ci)) {
+                    c = oc;
+                    ci = oi;
+                }
+            }
+            if (ci != 0xffffffffu) {
+                const uint32_t ax = (axes >> (2u * (ci / 64u))) & 3u;
+                const float extent = ax == 0 ? ex : (ax == 1 ? ey : ez);
+                const float lo_bound = ax == 0 ? box[0] : (ax == 1 ? box[1] : box[2]);
+                best_cost = c;
+                best_axis = ax;
+                const float step = 1.0f / static_cast<float>(nb);
+                best_plane = lo_bound + extent * step * (1.0f + static_cast<float>(ci & 63u)); // bvh.rs:130
+            }
+            __syncthreads();
+        }
+        for (uint32_t g0 = 0; g0 < n_axes && !lone && !direct; g0 += per_pass) { // wave-uniform
             const uint32_t in_pass = min(per_pass, n_axes - g0);
             for (int k = 0; k < 7; ++k) s_bins[k][lane] = 0;
             __syncthreads();
