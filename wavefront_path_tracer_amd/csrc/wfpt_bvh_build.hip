@@ -10,9 +10,10 @@
 //     destination follows from prefix counts;
 //   * node numbers are the order of split events in a depth-first walk: the tree is built breadth-first with
 //     provisional numbers and renumbered from subtree sizes at the end.
-// Large nodes are processed level by level, 1024-primitive chunks per workgroup, bins reduced with atomics on
-// order-preserving integer images of the floats. A node with <= 64 primitives (and <= 64 bins) is finished by
-// ONE wave that runs bvh.rs's recursion for the whole subtree out of LDS.
+// Large nodes are processed level by level, 1024-primitive chunks per workgroup over per-primitive records that move
+// with the partition, bins reduced with atomics on order-preserving integer images of the floats, one wave per node
+// for the sweep. A node with <= 64 primitives (and <= 64 bins) is finished by ONE wave that runs bvh.rs's recursion
+// for the whole subtree out of LDS.
 // Caveat: a bound that sees both +0 and -0 takes -0 as the minimum / +0 as the maximum here, while the host's
 // fmin/fmax keep whichever came first; inputs without negative zeros are unaffected.
 #include "wfpt_kernels.h"
