@@ -8,6 +8,15 @@ import sys
 import numpy as np
 import pytest
 
+# The PyTorch ROCm wheel ships its own libamdhip64; libwfpt.so links the system one. Whichever is loaded first serves
+# both (same SONAME), and only "torch first" works: with libwfpt first, torch later finds "No HIP GPUs" (seen on the
+# GPU box when tests/test_gpu_parity.py ran on its own). bench.py imports torch first for the same reason. Tests that
+# hand device pointers to torch (tiles.assemble_torch, the gloo tests) need it; the product itself never imports torch.
+try:
+    import torch  # noqa: F401  (must precede the first load of libwfpt.so in this process)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

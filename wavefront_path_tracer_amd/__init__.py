@@ -93,6 +93,10 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _lib_loaded():
+    return _lib is not None
+
+
 def lib():
     """Load libwfpt.so. Fails loudly when the HIP extension has not been built: nothing here can run without it."""
     global _lib

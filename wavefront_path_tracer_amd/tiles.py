@@ -41,10 +41,24 @@ def assemble(slabs, width, height):
     return out.reshape(-1, 3)
 
 
+def _torch():
+    """PyTorch, for the collective and the device-side assembly only. Its ROCm wheel bundles its own HIP runtime under
+    the SONAME libwfpt.so also links, so in one process the first of the two to load serves both, and only "torch
+    first" works: fail with that advice instead of torch's "No HIP GPUs are available"."""
+    import sys
+    loaded_before = "torch" in sys.modules
+    import torch
+    from . import _lib_loaded
+    if not loaded_before and _lib_loaded() and not torch.cuda.is_available():
+        raise RuntimeError("import torch before the first wavefront_path_tracer_amd call in this process: libwfpt.so was "
+                           "loaded first and PyTorch's bundled HIP runtime now sees no GPU")
+    return torch
+
+
 def assemble_torch(slabs, width, height):
     """`assemble` on whatever device the slabs live on: one strided copy per rank, no host round trip.
     slabs[r] is a flat float32 tensor holding rank r's bands; returns a (height, width, 3) tensor."""
-    import torch
+    torch = _torch()
     world = len(slabs)
     n_bands = (height + 7) // 8
     out = torch.empty((n_bands, 8, width, 3), dtype=torch.float32, device=slabs[0].device)
@@ -63,7 +77,7 @@ def gather_slabs(local_slab, rank, world, width, height, device=None, group=None
     (width*height, 3) image on rank 0 and None elsewhere. With keep_on_device the de-interleave runs on the
     device the slabs were gathered to and a (height, width, 3) torch tensor is returned (no host copy).
     """
-    import torch
+    torch = _torch()
     import torch.distributed as dist
 
     max_floats = 3 * max(slab_pixels(r, world, width, height) for r in range(world))
