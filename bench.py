@@ -243,7 +243,7 @@ def main():
                            "algorithmic_bytes_per_launch": round(per_launch_bytes, 1),
                            "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["ext_n"],
                            "note": ("extend is VALU-issue bound (LDS-resident BVH, ~55 % lane utilisation), not HBM-bound; see DESIGN.md"
-                                    if args.scene == "shirley" else "BVH read from HBM / Infinity Cache through L2; time is proportional to the 16-byte vector loads per lane-step (DESIGN.md section 8)")}
+                                    if args.scene == "shirley" else "BVH read from HBM / Infinity Cache through L2; bound by random 64-byte-line throughput behind the L1 (DESIGN.md section 8)")}
         out["stage_ms"] = stage["ms"]
         out["stage_launches"] = stage["launches"]
         out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)
