@@ -130,8 +130,9 @@ def main():
     mode_name = args.rng_mode if args.rng_mode != "auto" else ("dispatch" if world == 1 else "pixel")
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
     flags = (W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0)
-    # samples in flight per launch: 16 at N=1; each rank of N holds 1/N of the pixels, so scale it to keep launches as large
-    batch = args.batch or min(64, 16 * world)
+    # samples in flight per launch: 32 at N=1 (16 -> 32 -> 64: 13.5 -> 14.0 -> 14.1 Grays/s, mostly fewer scan launches);
+    # each rank of N holds 1/N of the pixels, so scale it to keep launches as large
+    batch = args.batch or min(64, 32 * world)
     kw = dict(seed=args.seed, max_wavefronts=args.bounces, rng_mode=rng_mode, flags=flags, tile_rank=rank,
               tile_world=world, device=gpu_index, batch=batch)
     if args.scene == "mesh":

@@ -2,7 +2,11 @@
 """Condenses rocprofv3 CSV output (gpurun_out/prof_*/<host>/*_{kernel_stats,counter_collection}.csv) into the
 small summaries committed under profiles/.
 
-    python profiles/summarize_rocprof.py gpurun_out r01
+    python profiles/summarize_rocprof.py gpurun_out r01 [n_pixels [samples per accumulate launch, comma separated]]
+
+Expects gpurun_out/prof_{stats,fetch,write,sq,sq2}/<host>/..., as written by
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py ...   (one pass per counter group)
 
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc.json
 (per-kernel mean counter values per launch) and profiles/<tag>_pmc_extend.json (HBM bytes per extend launch,
@@ -45,8 +49,9 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     n_pixels = int(sys.argv[3]) if len(sys.argv) > 3 else 1920 * 1080
     # samples per accumulate launch, in launch order (an accumulate launch of b samples reads (b + 1) * 12 B/pixel).
-    # Default = what `bench.py --steps 64 --warmup 16` does: warm-up 16, prime 16, 4 x 16 timed, 4 x 16 timed again.
-    acc_batches = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [16] * 10
+    # Default = what `bench.py --steps 64 --warmup 32` does with its 32 samples in flight: warm-up 32, prime 32,
+    # 2 x 32 timed, 2 x 32 timed again.
+    acc_batches = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [32] * 6
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
     if stats:
@@ -70,8 +75,9 @@ def main():
             "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
             "fetch_calibration_on_accumulate": cal,
             "accumulate_WRITE_SIZE_KiB_mean": acc.get("WRITE_SIZE", {}).get("mean"),
-            "note": "means over every extend launch of `python3 bench.py --steps 64 --warmup 16 --no-cpu-baseline` "
-                    "(every launch carries 16 samples); FETCH_SIZE x fetch_calibration (gfx950 reports half the read bytes; "
+            "note": "means over every extend launch of `python3 bench.py --steps 64 --warmup %d --no-cpu-baseline` "
+                    "(every launch carries %s samples); FETCH_SIZE x fetch_calibration (gfx950 reports half the read bytes; "
+                    % (acc_batches[0], "/".join(str(b) for b in sorted(set(acc_batches)))) +
                     "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE is exact",
             "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024.0,
             "hbm_bytes_per_launch": ((cal or 1.0) * fetch_kib + write_kib) * 1024.0,
