@@ -70,6 +70,7 @@ def main():
         case, acc = render_case("simple", w, h, 4, 4, mode, 4)
         np.savez_compressed(os.path.join(HERE, f"simple_64x64_mode{mode}.npz"), rays=rays, hits=hits, misses=misses,
                             ext=ext, image_after_first_wavefront=image, acc=acc, **case)
+    simple_wide()
     # (2) the seeded Shirley scene itself
     sp, mt = O.scene_book_one_final(1)
     sp2, nodes = O.build_bvh(sp)
@@ -81,6 +82,13 @@ def main():
             case, _ = render_case("shirley", w, h, spp, bounces, mode, ds)
             np.savez_compressed(os.path.join(HERE, f"shirley_{w}x{h}_mode{mode}.npz"), **case)
             print(w, h, mode, case["acc_sha256"][:16], case["totals"])
+
+
+def simple_wide():
+    # (1b) the same 5-sphere scene at 128x72 (SURVEY 8c fixture list): image + per-bounce tables
+    for mode in (0, 1):
+        case, acc = render_case("simple", 128, 72, 4, 4, mode, 4)
+        np.savez_compressed(os.path.join(HERE, f"simple_128x72_mode{mode}.npz"), acc=acc, **case)
 
 
 def mesh_golden():

@@ -238,11 +238,12 @@ def test_golden_small_cases_on_gpu(gpu):
     import os
     W = gpu
     for mode in (0, 1):
-        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"simple_64x64_mode{mode}.npz"))
-        pt = make_tracer(W, "simple", 64, 64, max_wavefronts=4, rng_mode=mode)
-        pt.render(4)
-        assert_bit_equal(pt.accumulated(), g["acc"], "golden 64x64 image")
-        pt.close()
+        for (w, h) in ((64, 64), (128, 72)):
+            g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"simple_{w}x{h}_mode{mode}.npz"))
+            pt = make_tracer(W, "simple", w, h, max_wavefronts=4, rng_mode=mode)
+            pt.render(4)
+            assert_bit_equal(pt.accumulated(), g["acc"], f"golden {w}x{h} image")
+            pt.close()
 
 
 def test_error_paths(gpu):
