@@ -188,6 +188,13 @@ int wfpt_build_bvh_device(wfpt_sphere *spheres, uint32_t n_spheres, wfpt_bvh_nod
 int wfpt_build_bvh_triangles_device(wfpt_triangle *triangles, uint32_t n_triangles, wfpt_bvh_node *nodes,
                                     uint32_t node_capacity, uint32_t *n_nodes, uint32_t n_bins, int device,
                                     float *device_ms);
+/* Build extension (README.md:25 "start loading in obj files"): reads the `v` and `f` records of a
+ * Wavefront OBJ file into wfpt_triangle (v0, e1 = v1 - v0, e2 = v2 - v0), fan-triangulating polygons; `f` entries may
+ * be `i`, `i/t`, `i//n` or `i/t/n`, 1-based or negative (relative). Every triangle gets `material_idx` /
+ * `material_type`. With triangles == NULL it only counts. Returns WFPT_OK and the count in *n_triangles;
+ * WFPT_ERR_INVALID_ARGUMENT for an unreadable file, a bad index or too small a capacity. */
+int wfpt_load_obj(const char *path, wfpt_triangle *triangles, uint32_t capacity, uint32_t *n_triangles,
+                  uint32_t material_idx, uint32_t material_type);
 /* BASELINE config 5: seeded triangle soup -- centres U[-10,10]^3, edges U[-0.05,0.05]^3, material i % 3 over
  * {Lambertian 0.7, Metal 0.8 fuzz 0.1, Dielectric 1.5}. Writes n triangles and 3 materials; returns 3. */
 uint32_t wfpt_scene_random_mesh(uint64_t seed, uint32_t n_triangles, wfpt_triangle *triangles, wfpt_material *materials);

@@ -169,8 +169,12 @@ uint32_t orc_scene_book_one_final(uint64_t seed, orc_sphere *sp, orc_material *m
 
 typedef struct { v3 mn, mx; uint32_t prim_count; } orc_bin;
 
-static inline float fmin_(float a, float b) { return a < b ? a : b; } /* operands never NaN here */
-static inline float fmax_(float a, float b) { return a > b ? a : b; }
+/* Box growth. glam's Vec3::min / max (f32::min / max) may return either zero for (+0, -0), so the reference leaves
+ * the sign of a zero bound open and a sequential fold would make it depend on the primitive order. Fixed here (and in
+ * the product's host and device builders) order-independently: the minimum prefers -0, the maximum +0. Operands are
+ * never NaN here. */
+static inline float fmin_(float a, float b) { return a < b ? a : (b < a ? b : (signbit(a) ? a : b)); }
+static inline float fmax_(float a, float b) { return a > b ? a : (b > a ? b : (signbit(a) ? b : a)); }
 static void bin_default(orc_bin *b) { /* bvh.rs:12-20 */
     b->mn = v3_make(INFINITY, INFINITY, INFINITY);
     b->mx = v3_make(-INFINITY, -INFINITY, -INFINITY);

@@ -90,6 +90,11 @@ def test_degenerate_inputs(gpu, n, n_bins):
     for f in ("v0", "e1", "e2"):
         flat[f][:, 1] = 0.0  # everything in the plane y = 0: one axis is narrower than 1e-5 and is skipped
     check(*both_mesh_builds(W, flat, n_bins), "flat mesh")
+    zeros = tris.copy()
+    rng = np.random.default_rng(3)
+    for f in ("v0", "e1", "e2"):  # +0 / -0 mixes in every box: the builders fix min -> -0, max -> +0 (wfpt_host.cpp zmin / zmax)
+        zeros[f][:, 2] = np.where(rng.random(n) < 0.5, np.float32(0.0), np.float32(-0.0))
+    check(*both_mesh_builds(W, zeros, n_bins), "signed zeros")
 
 
 @pytest.mark.gpu

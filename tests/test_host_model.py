@@ -141,3 +141,67 @@ def test_tonemap(wf, orc):
     got = wf.tonemap_rgb8(acc, 4)  # sqrt(acc / 4) -> 0, 1, 2->clamp, .5, clamp, .75
     assert got.tolist() == [[0, 255, 255], [128, 255, 191]]
     assert np.array_equal(got, orc.tonemap_rgb8(acc, 4))
+
+
+CUBE_OBJ = """# unit cube, one quad per face, mixed index forms
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+v 1 0 1
+v 1 1 1
+v 0 1 1
+vn 0 0 1
+f 1 2 3 4
+f 5/1 6/2 7/3 8/4
+f 1//1 2//1 6//1 5//1
+f 2/1/1 3/2/1 7/3/1 6/4/1
+f -6 -5 -1 -2
+f 4 1 5 8
+"""
+
+
+def test_obj_loader(wf, tmp_path):
+    """README.md:25 "start loading in obj files" (build extension): v / f records, polygons fanned, 1-based and
+    negative indices, i, i/t, i//n, i/t/n forms."""
+    path = tmp_path / "cube.obj"
+    path.write_text(CUBE_OBJ)
+    sc = wf.Scene.from_obj(str(path))
+    t = sc.triangles
+    assert len(t) == 12 and sc.materials[0]["material_type"] == 0
+    # first quad 1 2 3 4 -> (1,2,3), (1,3,4)
+    assert np.array_equal(t["v0"][0], [0, 0, 0]) and np.array_equal(t["e1"][0], [1, 0, 0]) and np.array_equal(t["e2"][0], [1, 1, 0])
+    assert np.array_equal(t["e1"][1], [1, 1, 0]) and np.array_equal(t["e2"][1], [0, 1, 0])
+    # "-6 -5 -1 -2" with 8 vertices read = 3 4 8 7 -> v0 = (1,1,0)
+    assert np.array_equal(t["v0"][8], [1, 1, 0]) and np.array_equal(t["e1"][8], [-1, 0, 0])
+    # the twelve triangles close the cube: total area 6, every face normal axis-aligned
+    n = np.cross(t["e1"], t["e2"])
+    assert np.isclose(0.5 * np.linalg.norm(n, axis=1).sum(), 6.0)
+    assert np.all(np.sort(np.abs(n), axis=1)[:, :2] == 0)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")  # index past the vertices read so far
+    with pytest.raises(wf.WfptError):
+        wf.Scene.from_obj(str(bad))
+    with pytest.raises(wf.WfptError):
+        wf.Scene.from_obj(str(tmp_path / "missing.obj"))
+
+
+def test_builders_agree_on_signed_zeros(wf, orc):
+    """f32::min / max may return either zero for (+0, -0) (bvh.rs:23-27 via glam), so a zero bound's sign is open in
+    the reference; oracle and host builder both take -0 as minimum and +0 as maximum, whatever the primitive order."""
+    sc = wf.Scene.random_mesh(600, seed=4)
+    t = sc.triangles
+    rng = np.random.default_rng(0)
+    for f in ("v0", "e1", "e2"):  # flatten z and sprinkle both zeros: boxes then contain (+0, -0) mixes
+        t[f][:, 2] = np.where(rng.random(len(t)) < 0.5, np.float32(0.0), np.float32(-0.0))
+    a, b = t.copy(), t.copy().view(orc.TRIANGLE)
+    host = wf.BVHTree(len(a))
+    host.build_bvh_tree_triangles(a, 16)
+    _, nodes = orc.build_bvh_triangles(b, 16)
+    assert host.nodes.tobytes() == nodes.tobytes()
+    assert np.signbit(host.nodes["aabb_min"][0][2]) and not np.signbit(host.nodes["aabb_max"][0][2])
+    shuffled = t.copy()[rng.permutation(len(t))]
+    other = wf.BVHTree(len(shuffled))
+    other.build_bvh_tree_triangles(shuffled, 16)
+    assert other.nodes[0].tobytes() == host.nodes[0].tobytes()  # the root box does not depend on the order

@@ -115,6 +115,7 @@ def lib():
         "wfpt_build_bvh_triangles": (i32, [vp, u32, vp, u32, C.POINTER(u32), u32]),
         "wfpt_build_bvh_device": (i32, [vp, u32, vp, u32, C.POINTER(u32), i32, C.POINTER(f32)]),
         "wfpt_build_bvh_triangles_device": (i32, [vp, u32, vp, u32, C.POINTER(u32), u32, i32, C.POINTER(f32)]),
+        "wfpt_load_obj": (i32, [C.c_char_p, vp, u32, C.POINTER(u32), u32, u32]),
         "wfpt_scene_random_mesh": (u32, [C.c_uint64, u32, vp, vp]),
         "wfpt_create_mesh": (vp, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]),
         "wfpt_camera_new": (None, [vp, vp, C.POINTER(f32), C.POINTER(f32)]),
@@ -229,6 +230,25 @@ class Scene:
         self.spheres = np.ascontiguousarray(spheres, SPHERE)
         self.materials = np.ascontiguousarray(materials, MATERIAL)
         self.triangles = None if triangles is None else np.ascontiguousarray(triangles, TRIANGLE)  # build extension
+
+    @classmethod
+    def from_obj(cls, path, materials=None, material_idx=0):
+        """Build extension (README.md:25): the triangles of a Wavefront OBJ file, all with one material
+        (default: Lambertian 0.7 grey, like the mesh scene's first material)."""
+        if materials is None:
+            materials = np.zeros(1, MATERIAL)
+            materials["albedo"][0] = (0.7, 0.7, 0.7, 1.0)
+        materials = np.ascontiguousarray(materials, MATERIAL)
+        n = C.c_uint32()
+        st = lib().wfpt_load_obj(os.fsencode(path), None, 0, C.byref(n), 0, 0)
+        if st != 0 or n.value == 0:
+            raise WfptError(st or ERR_INVALID_ARGUMENT, f"cannot read triangles from {path}")
+        tris = np.zeros(n.value, TRIANGLE)
+        mtype = int(materials["material_type"][material_idx])
+        st = lib().wfpt_load_obj(os.fsencode(path), _p(tris), len(tris), C.byref(n), material_idx, mtype)
+        if st != 0:
+            raise WfptError(st, f"cannot read triangles from {path}")
+        return cls(np.zeros(0, SPHERE), materials, triangles=tris)
 
     @classmethod
     def random_mesh(cls, n_triangles, seed=1):

@@ -14,8 +14,8 @@
 // with the partition, bins reduced with atomics on order-preserving integer images of the floats, one wave per node
 // for the sweep. A node with <= 64 primitives (and <= 64 bins) is finished by ONE wave that runs bvh.rs's recursion
 // for the whole subtree out of LDS.
-// Caveat: a bound that sees both +0 and -0 takes -0 as the minimum / +0 as the maximum here, while the host's
-// fmin/fmax keep whichever came first; inputs without negative zeros are unaffected.
+// Zeros: the minimum of (+0, -0) is -0 and the maximum +0, here (the integer image orders them that way) and in the host
+// builder alike (wfpt_host.cpp zmin / zmax); the reference's f32::min / max leave that choice open.
 #include "wfpt_kernels.h"
 
 #include <chrono>
@@ -47,6 +47,9 @@ __device__ __forceinline__ uint32_t enc_lo(float f) { return ~ord(f); }
 __device__ __forceinline__ uint32_t enc_hi(float f) { return ord(f); }
 __device__ __forceinline__ float dec_lo(uint32_t v) { return v == 0u ? __builtin_inff() : unord(~v); }
 __device__ __forceinline__ float dec_hi(uint32_t v) { return v == 0u ? -__builtin_inff() : unord(v); }
+// the same order on floats: -0 below +0 (wfpt_host.cpp zmin / zmax); operands are never NaN
+__device__ __forceinline__ float zmin(float a, float b) { return a < b ? a : (b < a ? b : (__float_as_uint(a) >> 31 ? a : b)); }
+__device__ __forceinline__ float zmax(float a, float b) { return a > b ? a : (b > a ? b : (__float_as_uint(a) >> 31 ? b : a)); }
 
 struct BuildNode { // provisional (breadth-first) node
     uint32_t lo[3]; // enc_lo
@@ -179,8 +182,8 @@ __global__ __launch_bounds__(kBuildThreads) void prep_prims_kernel(const void *p
             const wfpt_triangle t = static_cast<const wfpt_triangle *>(prims)[i];
             for (int a = 0; a < 3; ++a) {
                 const float va = t.v0[a], vb = t.v0[a] + t.e1[a], vc = t.v0[a] + t.e2[a];
-                lo[a] = fminf(fminf(va, vb), vc);
-                hi[a] = fmaxf(fmaxf(va, vb), vc);
+                lo[a] = zmin(zmin(va, vb), vc);
+                hi[a] = zmax(zmax(va, vb), vc);
                 k[a] = t.v0[a] + (t.e1[a] + t.e2[a]) * 0.33333334f;
             }
         }
@@ -296,8 +299,8 @@ struct SweepBox {
         n = 0;
     }
     __device__ __forceinline__ void grow(const SweepBox &o) {
-        lx = fminf(lx, o.lx); ly = fminf(ly, o.ly); lz = fminf(lz, o.lz);
-        hx = fmaxf(hx, o.hx); hy = fmaxf(hy, o.hy); hz = fmaxf(hz, o.hz);
+        lx = zmin(lx, o.lx); ly = zmin(ly, o.ly); lz = zmin(lz, o.lz);
+        hx = zmax(hx, o.hx); hy = zmax(hy, o.hy); hz = zmax(hz, o.hz);
         n += o.n;
     }
     __device__ __forceinline__ float area() const { return half_area(lx, ly, lz, hx, hy, hz); }
@@ -358,13 +361,13 @@ __global__ __launch_bounds__(kBuildThreads) void split_kernel(BuildArgs A) {
                 q.n = s_cnt[1][t + d];
             }
             __syncthreads();
-            s_box[0][0][t] = fminf(s_box[0][0][t], p.lx); s_box[0][1][t] = fminf(s_box[0][1][t], p.ly);
-            s_box[0][2][t] = fminf(s_box[0][2][t], p.lz); s_box[0][3][t] = fmaxf(s_box[0][3][t], p.hx);
-            s_box[0][4][t] = fmaxf(s_box[0][4][t], p.hy); s_box[0][5][t] = fmaxf(s_box[0][5][t], p.hz);
+            s_box[0][0][t] = zmin(s_box[0][0][t], p.lx); s_box[0][1][t] = zmin(s_box[0][1][t], p.ly);
+            s_box[0][2][t] = zmin(s_box[0][2][t], p.lz); s_box[0][3][t] = zmax(s_box[0][3][t], p.hx);
+            s_box[0][4][t] = zmax(s_box[0][4][t], p.hy); s_box[0][5][t] = zmax(s_box[0][5][t], p.hz);
             s_cnt[0][t] += p.n;
-            s_box[1][0][t] = fminf(s_box[1][0][t], q.lx); s_box[1][1][t] = fminf(s_box[1][1][t], q.ly);
-            s_box[1][2][t] = fminf(s_box[1][2][t], q.lz); s_box[1][3][t] = fmaxf(s_box[1][3][t], q.hx);
-            s_box[1][4][t] = fmaxf(s_box[1][4][t], q.hy); s_box[1][5][t] = fmaxf(s_box[1][5][t], q.hz);
+            s_box[1][0][t] = zmin(s_box[1][0][t], q.lx); s_box[1][1][t] = zmin(s_box[1][1][t], q.ly);
+            s_box[1][2][t] = zmin(s_box[1][2][t], q.lz); s_box[1][3][t] = zmax(s_box[1][3][t], q.hx);
+            s_box[1][4][t] = zmax(s_box[1][4][t], q.hy); s_box[1][5][t] = zmax(s_box[1][5][t], q.hz);
             s_cnt[1][t] += q.n;
             __syncthreads();
         }

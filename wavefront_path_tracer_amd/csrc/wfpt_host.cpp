@@ -8,6 +8,8 @@
 #include "wfpt.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -19,8 +21,13 @@ struct Vec3 {
     float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
 };
 inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline Vec3 vmin(Vec3 a, Vec3 b) { return {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}; }
-inline Vec3 vmax(Vec3 a, Vec3 b) { return {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}; }
+// Box growth (glam Vec3::min / max). For (+0, -0) f32::min / max may return either zero, so the reference leaves the sign
+// of a zero bound open; it is fixed here order-independently -- the minimum prefers -0, the maximum +0 -- which is also
+// what the device builder's integer atomics give. NaN operands: the other one (fmin / fmax semantics).
+inline float zmin(float a, float b) { return a != a ? b : (b != b ? a : (a < b ? a : (b < a ? b : (std::signbit(a) ? a : b)))); }
+inline float zmax(float a, float b) { return a != a ? b : (b != b ? a : (a > b ? a : (b > a ? b : (std::signbit(a) ? b : a)))); }
+inline Vec3 vmin(Vec3 a, Vec3 b) { return {zmin(a.x, b.x), zmin(a.y, b.y), zmin(a.z, b.z)}; }
+inline Vec3 vmax(Vec3 a, Vec3 b) { return {zmax(a.x, b.x), zmax(a.y, b.y), zmax(a.z, b.z)}; }
 inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } // glam Vec3::dot
 inline float length(Vec3 a) { return std::sqrt(dot(a, a)); }
 // glam Vec3::cross
@@ -311,6 +318,60 @@ int wfpt_build_bvh_triangles(wfpt_triangle *tris, uint32_t n, wfpt_bvh_node *nod
     BvhBuilder<TrianglePrims> builder(TrianglePrims{tris}, nodes, static_cast<int>(n_bins < 2 ? 2 : n_bins));
     *n_nodes = builder.build(n);
     return WFPT_OK;
+}
+
+int wfpt_load_obj(const char *path, wfpt_triangle *tris, uint32_t capacity, uint32_t *n_tris, uint32_t material_idx,
+                  uint32_t material_type) {
+    if (!path || !n_tris) return WFPT_ERR_INVALID_ARGUMENT;
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) return WFPT_ERR_INVALID_ARGUMENT;
+    std::vector<Vec3> verts;
+    std::vector<long long> face;
+    uint32_t count = 0;
+    int status = WFPT_OK;
+    char line[4096];
+    while (status == WFPT_OK && std::fgets(line, sizeof line, f)) {
+        const char *p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            Vec3 v{0.0f, 0.0f, 0.0f};
+            if (std::sscanf(p + 1, "%f %f %f", &v.x, &v.y, &v.z) != 3) status = WFPT_ERR_INVALID_ARGUMENT;
+            verts.push_back(v);
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            face.clear();
+            char *q = const_cast<char *>(p + 1);
+            for (;;) {
+                while (*q == ' ' || *q == '\t') ++q;
+                if (*q == 0 || *q == '\n' || *q == '\r' || *q == '#') break;
+                char *end = nullptr;
+                long long idx = std::strtoll(q, &end, 10); // the vertex index; "/t/n" parts are skipped
+                if (end == q) { status = WFPT_ERR_INVALID_ARGUMENT; break; }
+                while (*end && *end != ' ' && *end != '\t' && *end != '\n' && *end != '\r') ++end;
+                q = end;
+                if (idx < 0) idx += static_cast<long long>(verts.size()); // relative to the vertices read so far
+                else idx -= 1;
+                if (idx < 0 || idx >= static_cast<long long>(verts.size())) { status = WFPT_ERR_INVALID_ARGUMENT; break; }
+                face.push_back(idx);
+            }
+            for (size_t k = 2; status == WFPT_OK && k < face.size(); ++k) { // fan around the first vertex
+                if (tris) {
+                    if (count >= capacity) { status = WFPT_ERR_INVALID_ARGUMENT; break; }
+                    const Vec3 a = verts[face[0]], b = verts[face[k - 1]], c = verts[face[k]];
+                    wfpt_triangle &t = tris[count];
+                    t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z;
+                    t.e1[0] = b.x - a.x; t.e1[1] = b.y - a.y; t.e1[2] = b.z - a.z;
+                    t.e2[0] = c.x - a.x; t.e2[1] = c.y - a.y; t.e2[2] = c.z - a.z;
+                    t.material_idx = material_idx;
+                    t.material_type = material_type;
+                    t._pad = 0;
+                }
+                count += 1;
+            }
+        }
+    }
+    std::fclose(f);
+    *n_tris = count;
+    return status;
 }
 
 uint32_t wfpt_scene_random_mesh(uint64_t seed, uint32_t n, wfpt_triangle *tris, wfpt_material *mt) {
