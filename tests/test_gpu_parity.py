@@ -383,6 +383,35 @@ def test_single_sphere_root_leaf(gpu, orc):
     pt.close(); o.close()
 
 
+@pytest.mark.parametrize("sample_number", [1, 3, 7])
+def test_nonzero_sample_number_takes_the_advance_path(gpu, orc, sample_number):
+    """generate_rays.wgsl:155-171 / shade.wgsl: `advance(state, sample_number * 10)` with its as-written bug (it only
+    accumulates while the remaining count equals 1). The shipped loop always passes 0 (SPF = 1, path_tracer.rs:301),
+    so this drives the kernels through the stage API with the frame uniform's sample_number set."""
+    W = gpu
+    w, h = 128, 72
+    n = w * h
+    o = make_oracle(orc, inputs_for(orc, "simple", w, h), w, h)
+    pt = make_tracer(W, "simple", w, h)
+    frame = W.GPUFrameBuffer.new(w, h, 5)
+    frame.set_sample_number(sample_number)
+    pt.set_frame(frame); o.set_frame(5, sample_number)
+    pt.reset_image(); o.reset_image()
+    pt.set_counters([0, 0, n]); o.set_counters([0, 0, n])
+    pt.generate_ray_kernel.run((w // 8, h // 8)); o.generate_rays(w // 8, h // 8, False)
+    assert_bit_equal(pt.rays(n), o.rays(n).view(W.RAY), "rays with a non-zero sample_number")
+    ext = W.workgroup_size_64(n)
+    pt.extend_kernel.run(ext); o.extend(*ext)
+    c = o.counters()
+    hits = int(c[1])
+    c[2] = 0
+    pt.set_counters(c); o.set_counters(c)
+    sh = W.workgroup_size_64(hits)
+    pt.shade_kernel.run(sh); o.shade(*sh)
+    assert_bit_equal(pt.extension_rays(hits), o.extension_rays(hits).view(W.RAY), "extension rays with a non-zero sample_number")
+    pt.close(); o.close()
+
+
 def _odd_rays(W, n, seed):
     """Rays generate_rays never makes: axis-parallel (1/0 = inf in the slab test), zero-length, huge / tiny / denormal
     magnitudes, origins inside spheres and exactly on box planes, NaN and infinite components."""
