@@ -97,6 +97,21 @@ def load_traffic():
     return best
 
 
+def load_valu_busy():
+    """VALU pipe occupancy of extend from the committed PMC summary (profiles/r01_pmc.json): the kernel's real bound.
+    A wave64 fp32 instruction occupies a SIMD's 32 lanes for 2 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            e = json.load(open(p))["extend_kernel"]
+            busy = e["SQ_ACTIVE_INST_VALU"]["mean"] * 2.0 / 1024.0 / (e["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+            lanes = e["SQ_THREAD_CYCLES_VALU"]["mean"] / e["SQ_ACTIVE_INST_VALU"]["mean"]
+            return {"valu_busy": round(busy, 4), "lanes_per_valu_instruction": round(lanes, 2), "source": os.path.relpath(p, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -245,6 +260,8 @@ def main():
                            "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["ext_n"],
                            "note": ("extend is VALU-issue bound (LDS-resident BVH, ~55 % lane utilisation), not HBM-bound; see DESIGN.md"
                                     if args.scene == "shirley" else "BVH read from HBM / Infinity Cache through L2; bound by random 64-byte-line throughput behind the L1 (DESIGN.md section 8)")}
+        if args.scene == "shirley":
+            out["roofline"]["secondary"] = load_valu_busy()  # measured under rocprofv3 --pmc for the same command
         out["stage_ms"] = stage["ms"]
         out["stage_launches"] = stage["launches"]
         out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)
