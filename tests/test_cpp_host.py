@@ -58,3 +58,38 @@ def test_cpp_path_tracer(gpu, exe, orc, tmp_path, mode):
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     assert_bit_equal(got, o.render(spp), f"C++ PathTracer ({mode})")
     o.close()
+
+
+@pytest.fixture(scope="module")
+def c_example(wf, tmp_path_factory):
+    """examples/wfpt_render.c: the C ABI from plain C99 (-Wall -Wextra -Werror), nothing but include/wfpt.h and libwfpt.so."""
+    out = tmp_path_factory.mktemp("c") / "wfpt_render"
+    pkg = os.path.join(ROOT, "wavefront_path_tracer_amd")
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "wfpt_render.c"), "-o", str(out), "-L", pkg, "-lwfpt", f"-Wl,-rpath,{pkg}",
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    subprocess.run(cmd, check=True)
+    return str(out)
+
+
+def test_c_example_fails_loudly_without_a_gpu(c_example, wf, tmp_path):
+    if wf.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([c_example, str(tmp_path / "x.ppm"), "64", "64", "1", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and not (tmp_path / "x.ppm").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_bvh", [0, 1])
+def test_c_example_renders_the_same_image(gpu, c_example, tmp_path, device_bvh):
+    W = gpu
+    w, h, spp, bounces = 200, 120, 3, 6
+    out = tmp_path / "c.ppm"
+    r = subprocess.run([c_example, str(out), str(w), str(h), str(spp), str(bounces), str(device_bvh)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    pt = W.shirley_path_tracer(w, h, max_wavefronts=bounces)
+    pt.render(spp)
+    ref = tmp_path / "py.ppm"
+    pt.save_ppm(str(ref))
+    pt.close()
+    assert out.read_bytes() == ref.read_bytes()
