@@ -1,0 +1,39 @@
+"""bench.py's N > 1 path on a one-GPU box: two ranks under torch.distributed.run share the GPU and exchange their
+slabs over gloo (`--dist-backend gloo`, a rehearsal mode; the driver's multi-GPU runs use RCCL with one GPU per
+rank). The gathered frame must be byte-identical to the single-rank frame in the pixel-keyed RNG mode, and rank 0 must
+print exactly one JSON line with the contract's fields."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+COMMON = ["--steps", "6", "--warmup", "2", "--width", "400", "--height", "225", "--bounces", "5", "--no-stage-times", "--no-cpu-baseline"]
+
+
+def last_json_line(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_rehearsal_equals_single_rank(gpu, tmp_path):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    one, two = tmp_path / "n1.ppm", tmp_path / "n2.ppm"
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, "--rng-mode", "pixel", "--dump", str(one)],
+                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", *COMMON, "--dist-backend", "gloo",
+                         "--dump", str(two)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    a, b = last_json_line(r1.stdout), last_json_line(r2.stdout)
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["config"]["rng_mode"] == "pixel" and b["scaling"] == "strong"
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert key in b
+    assert a["config"]["rays_traced"] == b["config"]["rays_traced"]  # the same rays, split over two ranks
+    assert one.read_bytes() == two.read_bytes()
