@@ -60,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, rng_mode):
+def cpu_baseline(args, rng_mode, gpu_frame=None):
     """The oracle (kind "port": the build's own CPU restatement of the reference's chain; the reference's
     cpu_wavefront_pt has no source) timed on this box's host cores, OpenMP, on a bounded sample of the SAME
     workload: same scene/seed/camera/size/bounces, fewer samples per pixel (Mrays/s is spp-invariant)."""
@@ -79,10 +79,17 @@ def cpu_baseline(args, rng_mode):
             break
     rays = int(o.totals()[0])
     cores = O.lib().orc_num_threads()
+    out = {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"{spp} of the workload's {args.steps} samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
+                     f"{rays} rays, {el:.1f} s, OpenMP x{cores})"}
+    # the oracle is the checker: when it got through all K samples in its time budget, its accumulated image is the
+    # image the timed GPU steps must have produced, bit for bit (outside the timed region, costs one comparison)
+    if gpu_frame is not None and spp == args.steps:
+        import numpy as np
+        same = np.array_equal(np.ascontiguousarray(o.accumulated()).view(np.uint32), np.ascontiguousarray(gpu_frame).view(np.uint32))
+        out["gpu_image_vs_oracle"] = "bit-identical" if same else "DIFFERENT"
     o.close()
-    return {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{spp} of the workload's {args.steps} samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
-                      f"{rays} rays, {el:.1f} s, OpenMP x{cores})"}
+    return out
 
 
 def load_traffic():
@@ -180,7 +187,7 @@ def main():
             pt.render(nb)
     if world > 1:
         gather()  # warm the communicator too
-    pt.reset_accumulated()
+    pt.reset_progress()  # the timed K steps are frames 1..K: the frames the oracle renders in the cpu_baseline leg
     sync()
     rays0 = pt.totals().copy()
     t0 = time.perf_counter()
@@ -266,7 +273,7 @@ def main():
         out["stage_launches"] = stage["launches"]
         out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, rng_mode)
+        out["cpu_baseline"] = cpu_baseline(args, rng_mode, frame)
     if args.dump and frame is not None:
         if hasattr(frame, "cpu"):
             frame = frame.cpu().numpy().reshape(-1, 3)

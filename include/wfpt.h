@@ -251,6 +251,9 @@ int wfpt_set_counters(wfpt_ctx *ctx, const uint32_t counters[16]);
 int wfpt_read_counters(wfpt_ctx *ctx, uint32_t counters[16]); /* blocking, like wgpu_state.rs:132-147 */
 int wfpt_reset_image(wfpt_ctx *ctx);       /* image <- 1.0 (path_tracer.rs:305-306) */
 int wfpt_reset_accumulated(wfpt_ctx *ctx); /* accumulated <- 0 (path_tracer.rs:248-250) */
+/* RenderProgress::reset (parameters.rs:92-95) + the accumulation clear above: the next sample is frame 1 again. What
+ * update_buffers does after a change (path_tracer.rs:248-250, 276) without re-uploading camera or matrices. */
+int wfpt_reset_progress(wfpt_ctx *ctx);
 int wfpt_clear_ray_queues(wfpt_ctx *ctx);  /* path_tracer.rs:309-310 */
 /* copy_buffer_to_buffer(extension_ray_buffer -> ray_buffer) (path_tracer.rs:348, wgpu_state.rs:115-130)
  * done as a pointer swap. */

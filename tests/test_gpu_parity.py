@@ -180,6 +180,20 @@ def test_interactive_camera_resets_accumulation(gpu, orc):
     pt.close(); o.close()
 
 
+def test_reset_progress_restarts_at_frame_one(gpu, orc):
+    """wfpt_reset_progress = RenderProgress::reset (parameters.rs:92-95) + the accumulation clear of path_tracer.rs:248-250."""
+    W = gpu
+    pt = make_tracer(W, "shirley", 200, 120, max_wavefronts=4)
+    pt.render(5)
+    assert W.lib().wfpt_frame(pt.handle) == 5
+    pt.reset_progress()
+    assert W.lib().wfpt_frame(pt.handle) == 0 and pt.render_progress.accumulated_samples() == 0
+    pt.render(3)
+    o = make_oracle(orc, inputs_for(orc, "shirley", 200, 120), 200, 120, max_wavefronts=4)
+    assert_bit_equal(pt.accumulated(), o.render(3), "frames 1..3 again after reset_progress")
+    pt.close(); o.close()
+
+
 def test_tile_sharding_pixel_mode(gpu, orc):
     """Bands of 8 rows dealt round-robin to `world` contexts reproduce the unsharded image in PIXEL mode."""
     from wavefront_path_tracer_amd import tiles

@@ -137,6 +137,7 @@ def lib():
         "wfpt_read_counters": (i32, [vp, vp]),
         "wfpt_reset_image": (i32, [vp]),
         "wfpt_reset_accumulated": (i32, [vp]),
+        "wfpt_reset_progress": (i32, [vp]),
         "wfpt_clear_ray_queues": (i32, [vp]),
         "wfpt_swap_ray_queues": (i32, [vp]),
         "wfpt_kernel_run": (i32, [vp, i32, u32, u32]),
@@ -639,6 +640,11 @@ class PathTracer:
 
     def reset_accumulated(self):
         self._check(lib().wfpt_reset_accumulated(self.handle))
+
+    def reset_progress(self):
+        """RenderProgress::reset + accumulation clear: the next sample is frame 1 again."""
+        self._check(lib().wfpt_reset_progress(self.handle))
+        self.render_progress.reset()
 
     def clear_ray_queues(self):
         self._check(lib().wfpt_clear_ray_queues(self.handle))

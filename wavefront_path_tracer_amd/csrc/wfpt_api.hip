@@ -755,6 +755,16 @@ int wfpt_reset_accumulated(wfpt_ctx *c) {
     return WFPT_OK;
 }
 
+int wfpt_reset_progress(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipMemsetAsync(c->accumulated, 0, sizeof(float) * 3 * static_cast<size_t>(c->pixel_capacity), c->stream)); // pt:248-250
+    c->progress_frame = 0; // RenderProgress::reset, pt:276
+    c->accumulated_samples = 0;
+    c->dev_frame_valid = false;
+    return WFPT_OK;
+}
+
 int wfpt_clear_ray_queues(wfpt_ctx *c) {
     if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
     WFPT_HIP(c, hipSetDevice(c->device));
