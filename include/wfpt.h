@@ -102,6 +102,36 @@ typedef struct wfpt_hit_payload {
     uint32_t mat_type;
 } wfpt_hit_payload;
 
+/* Compile-time layout checks: these are the byte layouts the reference uploads with bytemuck::cast_slice
+ * (path_tracer.rs:120-156) and declares in WGSL (extend.wgsl:3-29, shade.wgsl:19-24, generate_rays.wgsl:13-26). */
+#if defined(__cplusplus)
+#define WFPT_LAYOUT_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define WFPT_LAYOUT_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_sphere) == 32 && offsetof(wfpt_sphere, radius) == 16 && offsetof(wfpt_sphere, material_idx) == 20 &&
+                       offsetof(wfpt_sphere, material_type) == 24,
+                   "Sphere: sphere.rs:3-11, 32 bytes");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_material) == 32 && offsetof(wfpt_material, fuzz) == 16 && offsetof(wfpt_material, refract_index) == 20 &&
+                       offsetof(wfpt_material, material_type) == 24,
+                   "Material: material.rs:12-20, 32 bytes");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_bvh_node) == 32 && offsetof(wfpt_bvh_node, left_first) == 12 && offsetof(wfpt_bvh_node, aabb_max) == 16 &&
+                       offsetof(wfpt_bvh_node, prim_count) == 28,
+                   "BVHNode: bvh.rs:38-45, 32 bytes");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_triangle) == 48 && offsetof(wfpt_triangle, e1) == 16 && offsetof(wfpt_triangle, e2) == 32,
+                   "wfpt_triangle: three 16-byte rows");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_gpu_camera) == 32 && offsetof(wfpt_gpu_camera, pitch) == 16 && offsetof(wfpt_gpu_camera, yaw) == 20 &&
+                       offsetof(wfpt_gpu_camera, defocus_radius) == 24 && offsetof(wfpt_gpu_camera, focus_distance) == 28,
+                   "GPUCamera: camera_controller.rs:161-185, 32 bytes");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_frame_buffer) == 16 && offsetof(wfpt_frame_buffer, frame) == 8 && offsetof(wfpt_frame_buffer, sample_number) == 12,
+                   "GPUFrameBuffer: gpu_structs.rs:5-12, 16 bytes");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_ray) == 48 && offsetof(wfpt_ray, direction) == 16 && offsetof(wfpt_ray, inv_direction) == 32 &&
+                       offsetof(wfpt_ray, pixel_idx) == 44,
+                   "Ray: extend.wgsl:17-22, 48 bytes");
+WFPT_LAYOUT_ASSERT(sizeof(wfpt_hit_payload) == 16 && offsetof(wfpt_hit_payload, ray_idx) == 4 && offsetof(wfpt_hit_payload, sphere_idx) == 8 &&
+                       offsetof(wfpt_hit_payload, mat_type) == 12,
+                   "HitPayload: extend.wgsl:24-29, 16 bytes");
+
 /* ------------------------------------------------------------------ enums */
 
 typedef enum wfpt_status {
@@ -239,7 +269,10 @@ wfpt_ctx *wfpt_create_mesh(const wfpt_params *params,
 void wfpt_destroy(wfpt_ctx *ctx);
 const char *wfpt_last_error(const wfpt_ctx *ctx);
 
-/* frame_buffer.queue_for_gpu (path_tracer.rs:296-297, 366-367) */
+/* frame_buffer.queue_for_gpu (path_tracer.rs:296-297, 366-367). The uniform set here is what the STAGE API
+ * (wfpt_kernel_run) reads. The device-resident loop (wfpt_render_sample / wfpt_render) owns the frame uniform like
+ * PathTracer::run does (path_tracer.rs:293-297): its next call overwrites it with {width, height,
+ * wfpt_frame() + 1, sample_number 0}, whatever was set here. */
 int wfpt_set_frame(wfpt_ctx *ctx, const wfpt_frame_buffer *frame);
 /* update_buffers (path_tracer.rs:240-277): new camera / matrices / viewport; zeroes the accumulated image
  * and resets progress exactly as the reference does on any parameter change. */

@@ -516,7 +516,9 @@ def test_device_side_slab_assembly(gpu):
     for rank in range(world):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=2)
         pt.render(spp)
+        # the fill runs on torch's stream, the copy on the context's: drain torch's stream first
         t = torch.zeros(pad, dtype=torch.float32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
         pt.copy_accumulated_to_device(t.data_ptr(), 12 * tiles.slab_pixels(rank, world, w, h))
         slabs.append(t)
         pt.close()

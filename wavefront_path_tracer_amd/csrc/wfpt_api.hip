@@ -355,9 +355,14 @@ int render_batch(wfpt_ctx *c, uint32_t nb) {
             WFPT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             const int r = enqueue_batch(c, nullptr, nb);
             const hipError_t e = hipStreamEndCapture(c->stream, &g);
-            if (r != WFPT_OK) return r;
-            if (e != hipSuccess) return hip_fail(c, e, "hipStreamEndCapture");
-            WFPT_HIP(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            if (r != WFPT_OK || e != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g); // a failed capture must not leak its partial graph
+                return r != WFPT_OK ? r : hip_fail(c, e, "hipStreamEndCapture");
+            }
+            if (const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0); ie != hipSuccess) {
+                (void)hipGraphDestroy(g);
+                return hip_fail(c, ie, "hipGraphInstantiate");
+            }
             it = c->graphs.emplace(nb, std::make_pair(g, ge)).first;
         }
         WFPT_HIP(c, hipGraphLaunch(it->second.second, c->stream));
@@ -786,13 +791,20 @@ int wfpt_kernel_run(wfpt_ctx *c, int stage, uint32_t gx, uint32_t gy) {
     if (threads64 == 0) return WFPT_OK; // an empty dispatch
     const uint32_t threads = threads64 > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(threads64);
     WFPT_HIP(c, hipSetDevice(c->device));
+    if (stage == WFPT_STAGE_GENERATE_RAYS) { // argument checks come before the start event is recorded
+        if (threads64 > c->capacity)
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch exceeds the ray buffer (max_pixels)");
+        // The literal dispatch writes pixel_idx = x + y * (8 gx) (gr:55-57), and shade / miss_kernel index the image with
+        // it: the reference relies on monitor-sized buffers and robust buffer access, here the dispatch must stay inside
+        // the image allocation (e.g. ceil(100/8)^2 tiles on a 100x100 context without max_pixels is refused).
+        if (threads64 > c->pixel_capacity)
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch exceeds the image buffer: 8*gx x 8*gy pixels > max_pixels");
+        if (static_cast<uint64_t>(gx) * 8u * gy * 8u * (c->tile.world) > (1ull << 32))
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch too large");
+    }
     if (int r = stage_begin(c, stage); r != WFPT_OK) return r;
     switch (stage) {
     case WFPT_STAGE_GENERATE_RAYS:
-        if (threads64 > c->capacity)
-            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch exceeds the ray buffer (max_pixels)");
-        if (static_cast<uint64_t>(gx) * 8u * gy * 8u * (c->tile.world) > (1ull << 32))
-            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "generate_rays dispatch too large");
         WFPT_HIP(c, launch_generate(generate_args(c, gx, gy, false), c->stream));
         break;
     case WFPT_STAGE_EXTEND:
@@ -951,6 +963,14 @@ int wfpt_write_rays(wfpt_ctx *c, const wfpt_ray *rays, uint32_t n) {
     if (!c || !rays) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: null argument");
     if (n > c->capacity) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: n exceeds the queue capacity");
     if (n == 0) return WFPT_OK;
+    // shade and miss_kernel index the image with the ray's pixel_idx: it must name a pixel this context holds
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t px = rays[i].pixel_idx;
+        if (px == WFPT_INACTIVE_PIXEL) continue;
+        bool ok = px < c->pixel_capacity;
+        if (c->tile.world > 1) ok = px < c->width * c->height && ((px / c->width) >> 3) % c->tile.world == c->tile.rank;
+        if (!ok) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: pixel_idx outside the image this context holds");
+    }
     WFPT_HIP(c, hipSetDevice(c->device));
     wfpt_ray *tmp = nullptr;
     WFPT_HIP(c, dmalloc(&tmp, n));

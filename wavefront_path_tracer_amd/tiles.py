@@ -83,10 +83,18 @@ def gather_slabs(local_slab, rank, world, width, height, device=None, group=None
     max_floats = 3 * max(slab_pixels(r, world, width, height) for r in range(world))
     mine = 3 * slab_pixels(rank, world, width, height)
     dev = torch.device("cpu") if device is None else device
-    send = torch.zeros(max_floats, dtype=torch.float32, device=dev)
+    # `send` is written twice: its tail by a torch fill (torch's current stream) and its head by the context's
+    # device-to-device copy (the context's own non-blocking stream). The two streams are not ordered with each other, so
+    # the regions are kept disjoint (torch never touches [0, mine)) and torch's stream is drained before the copy is
+    # queued: a late fill can then neither zero the slab nor race the collective that follows.
+    send = torch.empty(max_floats, dtype=torch.float32, device=dev)
+    if mine < max_floats:
+        send[mine:].zero_()
     if callable(local_slab):
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
         if mine:
-            local_slab(send.data_ptr(), 4 * mine)
+            local_slab(send.data_ptr(), 4 * mine)  # wfpt_copy_accumulated_to_device: returns after its stream has drained
     else:
         send[:mine] = torch.from_numpy(np.ascontiguousarray(local_slab, np.float32).reshape(-1)).to(dev)
     if world == 1:
