@@ -29,7 +29,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters"); the device-derived figure is reported beside it
+
+# algorithmic bytes per unit of work of each stage (minimal SoA chain, scene traffic excluded)
+B_EXTEND_RAY, B_EXTEND_HIT, B_EXTEND_MISS = 24.0, 12.0, 4.0  # extend: ray read; hit / miss written
+B_SHADE_HIT = 92.0                                           # shade: hit + ray gather + throughput RMW + extension ray
+B_MISS = 36.0                                                # miss_kernel: index + (dir.y, pixel) + throughput RMW
+B_GENERATE_PIXEL = 28.0 + 12.0                               # generate_rays: ray written + image reset folded in
 
 
 def parse():
@@ -48,6 +54,7 @@ def parse():
                     help="auto: dispatch (reference-faithful) on 1 GPU, pixel (shard-invariant) on N > 1")
     ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="run the stage kernels one by one (extend, scan, shade, miss_kernel per wavefront)")
     ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
@@ -89,31 +96,29 @@ def cpu_baseline(args, rng_mode, gpu_frame=None):
         same = np.array_equal(np.ascontiguousarray(o.accumulated()).view(np.uint32), np.ascontiguousarray(gpu_frame).view(np.uint32))
         out["gpu_image_vs_oracle"] = "bit-identical" if same else "DIFFERENT"
     o.close()
+    # single-thread figure: the serial twin of the oracle on one sample per pixel of the same frame
+    mk = O.mesh_oracle if args.scene == "mesh" else O.shirley_oracle
+    kw = dict(seed=args.seed, max_wavefronts=args.bounces, rng_mode=rng_mode, serial=True)
+    o1 = mk(args.width, args.height, args.triangles, **kw) if args.scene == "mesh" else mk(args.width, args.height, **kw)
+    t0 = time.perf_counter()
+    o1.render_sample()
+    el1 = time.perf_counter() - t0
+    out["single_thread"] = {"value": round(int(o1.totals()[0]) / el1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                            "sample": f"1 sample per pixel, {int(o1.totals()[0])} rays, {el1:.1f} s"}
+    out["build"] = "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile)"
+    o1.close()
     return out
 
 
-def load_traffic():
-    """HBM bytes per extend launch from the committed PMC summary, if one exists (profiles/*_pmc_extend.json)."""
+def load_pmc(scene, variant):
+    """Committed rocprofv3 --pmc summary of THIS workload and loop variant (profiles/r*_pmc_<scene>_<variant>.json,
+    written by profiles/summarize_rocprof.py from the same bench command), newest round first; None if there is none."""
     import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_extend*.json"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{scene}_{variant}.json")), reverse=True):
         try:
-            best = json.load(open(p))
-        except Exception:
-            pass
-    return best
-
-
-def load_valu_busy():
-    """VALU pipe occupancy of extend from the committed PMC summary (profiles/r01_pmc.json): the kernel's real bound.
-    A wave64 fp32 instruction occupies a SIMD's 32 lanes for 2 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks."""
-    import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
-        try:
-            e = json.load(open(p))["extend_kernel"]
-            busy = e["SQ_ACTIVE_INST_VALU"]["mean"] * 2.0 / 1024.0 / (e["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
-            lanes = e["SQ_THREAD_CYCLES_VALU"]["mean"] / e["SQ_ACTIVE_INST_VALU"]["mean"]
-            return {"valu_busy": round(busy, 4), "lanes_per_valu_instruction": round(lanes, 2), "source": os.path.relpath(p, ROOT)}
+            d = json.load(open(p))
+            d["source"] = os.path.relpath(p, ROOT)
+            return d
         except Exception:
             continue
     return None
@@ -151,7 +156,8 @@ def main():
 
     mode_name = args.rng_mode if args.rng_mode != "auto" else ("dispatch" if world == 1 else "pixel")
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
-    flags = (W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0)
+    flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
+             (W.FLAG_UNFUSED if args.unfused else 0))
     # samples in flight per launch: 32 at N=1 (16 -> 32 -> 64: 13.5 -> 14.0 -> 14.1 Grays/s, mostly fewer scan launches);
     # each rank of N holds 1/N of the pixels, so scale it to keep launches as large
     batch = args.batch or min(64, 32 * world)
@@ -208,26 +214,41 @@ def main():
     if world == 1:
         frame = pt.accumulated()
 
-    # ---- per-stage times and the extend roofline: same K steps again with hipEvent pairs around every
-    # launch on the context's stream (a second pass, so the events do not perturb `value`)
+    # ---- per-stage times and the roofline of the dominant kernel: same K steps again with hipEvent pairs around
+    # every launch on the context's stream (a second pass, so the events do not perturb `value`)
+    fused = not (args.split_shade or args.unfused)
     stage = None
     if not args.no_stage_times:
         ms = np.zeros(W.STAGE_COUNT, np.float64)
         launches = np.zeros(W.STAGE_COUNT, np.int64)
-        r0 = pt.totals().copy()
+        r0, w0 = pt.totals().copy(), pt.wavefront_totals().astype(np.float64)
         m, l = pt.render_timed(args.steps)  # same batching as pt.render
         ms += m
         launches += l
         rt = pt.totals() - r0
-        ext_ms, ext_n = float(ms[W.STAGES["extend"]]), int(launches[W.STAGES["extend"]])
-        # SURVEY 8(d)'s algorithmic figure: 24 B/ray in, 12 B/hit, 4 B/miss. (The kernel additionally hands miss_kernel
-        # (dir.y, pixel) through the miss queue: +12 B/miss, visible in the PMC traffic below.)
-        ext_bytes = 24.0 * float(rt[0]) + 12.0 * float(rt[1]) + 4.0 * float(rt[2])
+        wt = pt.wavefront_totals().astype(np.float64) - w0  # rows (rays traced, hits, misses) per wavefront over these K steps
         shade_ms = float(sum(ms[W.STAGES[k]] for k in ("shade", "shade_lambertian", "shade_metal", "shade_dielectric")))
+        if fused:
+            # dominant kernel: the middle bounce launches = shade(b-1) + extend(b) + miss_kernel(b-1), b = 1 .. max-1.
+            # Algorithmic bytes = SURVEY 8(d)'s per-unit figures times the units those launches process.
+            kname, kstage = "bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)", "bounce"
+            shaded, applied = wt[:-1, 1].sum(), wt[:-1, 2].sum()        # hits / misses of wavefronts 0 .. max-2
+            rays, hits_out, miss_out = wt[1:, 0].sum(), wt[1:, 1].sum(), wt[1:, 2].sum()
+            k_bytes = (B_SHADE_HIT * shaded + B_EXTEND_RAY * rays + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied)
+            # what the fused design itself has to move: record in (32), throughput RMW (24), record out (32) / miss out (8),
+            # applied miss (8 + 24) -- no extension-ray queue, no hit-queue gather
+            k_own = 56.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 32.0 * applied
+            chain_ms = float(sum(ms[W.STAGES[k]] for k in ("bounce_first", "bounce", "bounce_last", "scan")))
+        else:
+            kname, kstage = "extend_kernel", "extend"
+            k_bytes = B_EXTEND_RAY * float(rt[0]) + B_EXTEND_HIT * float(rt[1]) + B_EXTEND_MISS * float(rt[2])
+            k_own = k_bytes + 8.0 * float(rt[2])  # + (dir.y, pixel) handed to miss_kernel through the miss queue
+            chain_ms = float(ms[W.STAGES["extend"]] + ms[W.STAGES["scan"]]) + shade_ms
         stage = {"ms": {k: round(float(ms[v]), 4) for k, v in W.STAGES.items() if launches[v]},
                  "launches": {k: int(launches[v]) for k, v in W.STAGES.items() if launches[v]},
-                 "rays": int(rt[0]), "ext_ms": ext_ms, "ext_n": ext_n, "ext_bytes": ext_bytes,
-                 "extend_shade_mrays_s": float(rt[0]) / ((ext_ms + float(ms[W.STAGES["scan"]]) + shade_ms) * 1e-3) / 1e6}
+                 "kname": kname, "k_ms": float(ms[W.STAGES[kstage]]), "k_n": int(launches[W.STAGES[kstage]]),
+                 "k_bytes": float(k_bytes), "k_own": float(k_own), "rays": int(rt[0]),
+                 "extend_shade_mrays_s": float(rt[0]) / (chain_ms * 1e-3) / 1e6 if chain_ms > 0 else 0.0}
 
     if rank != 0:
         if dist is not None:
@@ -235,7 +256,7 @@ def main():
         return
 
     out = {
-        "metric": "Mrays/s (extend+shade) at 1920x1080, 64 spp, 8 bounces; 1/2/4/8 GPU",
+        "metric": f"Mrays/s (extend+shade) at {args.width}x{args.height}, {args.steps} spp, {args.bounces} bounces; 1/2/4/8 GPU",
         "value": round(float(rays_total[0]) / elapsed / 1e6, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -250,25 +271,39 @@ def main():
         "config": {"workload": f"{scene_name}, {args.width}x{args.height}, {args.steps} spp, {args.bounces} bounces",
                    "step": "one sample per pixel: generate_rays -> bounces x (extend, scan, shade, miss_kernel) -> accumulate",
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
-                   "launch": "direct" if args.no_graph else "hipGraph", "samples_in_flight": batch,
+                   "loop": "fused bounce launches" if fused else "stage kernels one by one",
+                   "launch": "direct" if args.no_graph else "hipGraph",
+                   "samples_in_flight": sorted({min(batch, args.steps), args.steps % batch} - {0}, reverse=True),
                    "parallelism": "single GPU" if world == 1 else
                    f"pixel bands of 8 rows over {world} ranks + 1 gather ({'RCCL' if not rehearsal else 'gloo REHEARSAL, ranks share GPUs'})",
                    "rays_traced": int(rays_total[0])},
     }
+    info = W.device_info(gpu_index)
+    # double data rate: 2 transfers per memory clock; what hipDeviceProp_t reports for this board, next to the spec figure
+    peak_device = 2.0 * info["memory_clock_khz"] * 1e3 * info["memory_bus_width_bits"] / 8.0 / 1e9
     if stage is not None:
-        per_launch_bytes = stage["ext_bytes"] / max(stage["ext_n"], 1)
-        avg_s = stage["ext_ms"] * 1e-3 / max(stage["ext_n"], 1)
+        per_launch_bytes = stage["k_bytes"] / max(stage["k_n"], 1)
+        avg_s = stage["k_ms"] * 1e-3 / max(stage["k_n"], 1)
         achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = load_traffic()
-        out["roofline"] = {"kernel": "extend_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        variant = "split" if args.split_shade else ("unfused" if args.unfused else "fused")
+        pmc = load_pmc(args.scene, variant)
+        # PMC traffic is a property of (scene, loop variant): the profile stores HBM bytes per algorithmic byte of the
+        # same kernel on the same workload, scaled here by this run's algorithmic bytes per launch; null without a profile
+        ratio = (pmc or {}).get("hbm_bytes_per_algorithmic_byte")
+        out["roofline"] = {"kernel": stage["kname"], "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                           "traffic": round(ratio * per_launch_bytes, 1) if ratio else None,
+                           "traffic_source": (pmc or {}).get("source"),
+                           "peak_device": round(peak_device, 1),
+                           "peak_device_source": f"hipDeviceProp_t: 2 x {info['memory_clock_khz']} kHz x {info['memory_bus_width_bits']} bit / 8",
                            "algorithmic_bytes_per_launch": round(per_launch_bytes, 1),
-                           "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["ext_n"],
-                           "note": ("extend is VALU-issue bound (LDS-resident BVH, ~55 % lane utilisation), not HBM-bound; see DESIGN.md"
-                                    if args.scene == "shirley" else "BVH read from HBM / Infinity Cache through L2; bound by random 64-byte-line throughput behind the L1 (DESIGN.md section 8)")}
-        if args.scene == "shirley":
-            out["roofline"]["secondary"] = load_valu_busy()  # measured under rocprofv3 --pmc for the same command
+                           "fused_design_bytes_per_launch": round(stage["k_own"] / max(stage["k_n"], 1), 1),
+                           "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["k_n"],
+                           "note": ("traversal is VALU-issue bound (LDS-resident BVH), not HBM-bound; see DESIGN.md section 4"
+                                    if args.scene == "shirley" else
+                                    "BVH read from HBM / Infinity Cache through L2; bound by random-line throughput behind the L1 (DESIGN.md section 8)")}
+        if pmc and "secondary" in pmc:
+            out["roofline"]["secondary"] = pmc["secondary"]  # VALU occupancy, active lanes: measured under rocprofv3 --pmc
         out["stage_ms"] = stage["ms"]
         out["stage_launches"] = stage["launches"]
         out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)

@@ -157,7 +157,12 @@ typedef enum wfpt_stage {
     WFPT_STAGE_SHADE_DIELECTRIC = 7,
     WFPT_STAGE_SCAN = 8, /* internal helper launched with extend (queue positions + loop control); only
                             appears in wfpt_render_sample_timed's per-stage times */
-    WFPT_STAGE_COUNT = 9
+    /* The device-resident loop's fused launches (not dispatchable through wfpt_kernel_run; they appear in the
+     * per-stage times of wfpt_render_timed). One launch per wavefront: */
+    WFPT_STAGE_BOUNCE_FIRST = 9,  /* "bounce_first": generate_rays + extend of wavefront 0 */
+    WFPT_STAGE_BOUNCE = 10,       /* "bounce": shade of wavefront b-1 + extend of wavefront b + miss_kernel of b-1 */
+    WFPT_STAGE_BOUNCE_LAST = 11,  /* "bounce_last": shade + miss_kernel of the last wavefront */
+    WFPT_STAGE_COUNT = 12
 } wfpt_stage;
 
 /* How shade keys its RNG (shade.wgsl:72 uses the dispatch's global_invocation_id):
@@ -170,7 +175,10 @@ typedef enum wfpt_rng_mode { WFPT_RNG_DISPATCH = 0, WFPT_RNG_PIXEL = 1 } wfpt_rn
 
 enum {
     WFPT_FLAG_SPLIT_SHADE = 1u << 0, /* fused loop runs the three per-material shade stages */
-    WFPT_FLAG_NO_GRAPH = 1u << 1     /* fused loop launches kernels directly instead of replaying a hipGraph */
+    WFPT_FLAG_NO_GRAPH = 1u << 1,    /* fused loop launches kernels directly instead of replaying a hipGraph */
+    WFPT_FLAG_UNFUSED = 1u << 2      /* device-resident loop runs the stage kernels one by one (extend, scan, shade,
+                                        miss_kernel per wavefront) instead of one fused bounce launch per wavefront.
+                                        Same images bit for bit; WFPT_FLAG_SPLIT_SHADE implies it. */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu
@@ -343,6 +351,13 @@ int wfpt_write_rays(wfpt_ctx *ctx, const wfpt_ray *rays, uint32_t n);
 int wfpt_read_bounce_table(wfpt_ctx *ctx, uint32_t *rows4, uint32_t max_rows, uint32_t *n_rows);
 /* Totals since creation over fused samples: [0] rays traced by extend, [1] hits, [2] misses. */
 int wfpt_read_totals(wfpt_ctx *ctx, uint64_t totals[3]);
+/* The same per wavefront: rows of (rays traced, hits, misses) summed over every fused sample since creation, one row
+ * per wavefront 0 .. max_wavefronts-1 (what a bench needs to price each launch of the loop in bytes). */
+int wfpt_read_wavefront_totals(wfpt_ctx *ctx, uint64_t *rows3, uint32_t max_rows, uint32_t *n_rows);
+/* hipDeviceProp_t facts a report needs: CU count, memory clock (kHz) and bus width (bits), memory size. Any output
+ * pointer may be NULL. Double-data-rate peak bandwidth = 2 * clock * width / 8. */
+int wfpt_device_info(int device, uint32_t *compute_units, uint32_t *memory_clock_khz, uint32_t *memory_bus_width_bits,
+                     uint64_t *total_memory_bytes);
 /* display_shader.wgsl:50-52 tone map, sqrt(acc / n_samples) -> 8-bit RGB (host side, for image dumps) */
 void wfpt_tonemap_rgb8(const float *accumulated, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb);
 

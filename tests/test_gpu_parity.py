@@ -102,7 +102,7 @@ CASES = [
 
 @pytest.mark.parametrize("kind,w,h,spp,bounces", CASES)
 @pytest.mark.parametrize("rng_mode", [0, 1])
-@pytest.mark.parametrize("flags", [0, 2])  # hipGraph replay / direct launches
+@pytest.mark.parametrize("flags", [0, 2, 4, 6])  # fused bounce launches: hipGraph replay / direct; 4 = WFPT_FLAG_UNFUSED: stage kernels one by one
 def test_device_resident_loop(gpu, orc, kind, w, h, spp, bounces, rng_mode, flags):
     W = gpu
     o = make_oracle(orc, inputs_for(orc, kind, w, h), w, h, rng_mode=rng_mode, max_wavefronts=bounces)
@@ -294,7 +294,7 @@ def test_batched_samples_equal_sequential(gpu, orc, batch):
     w, h, spp, bounces = 200, 120, 19, 5  # 19 = full batches plus a remainder rendered one by one
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    for flags in (0, W.FLAG_NO_GRAPH):
+    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")
@@ -304,7 +304,13 @@ def test_batched_samples_equal_sequential(gpu, orc, batch):
         ms, launches = pt.render_timed(batch)  # one more batch, timed: same results as untimed
         o2 = o.render(batch)
         assert_bit_equal(pt.accumulated(), o2, "render_timed")
-        assert launches[W.STAGES["extend"]] == bounces and ms[W.STAGES["extend"]] > 0
+        if flags & W.FLAG_UNFUSED:  # stage kernels one by one
+            assert launches[W.STAGES["extend"]] == bounces and ms[W.STAGES["extend"]] > 0
+            assert launches[W.STAGES["shade"]] == bounces and launches[W.STAGES["bounce"]] == 0
+        else:  # one fused launch per wavefront, plus the shade + miss of the last one
+            assert launches[W.STAGES["bounce_first"]] == 1 and launches[W.STAGES["bounce_last"]] == 1
+            assert launches[W.STAGES["bounce"]] == bounces - 1 and ms[W.STAGES["bounce"]] > 0
+            assert launches[W.STAGES["extend"]] == 0 and launches[W.STAGES["scan"]] == bounces
         want = o2
         spp_done = spp + batch
         pt.close()

@@ -24,19 +24,21 @@ from . import _build
 
 __all__ = ["SPP", "SPF", "Scene", "BVHTree", "Camera", "CameraController", "ProjectionMatrix", "GPUFrameBuffer",
            "RenderParameters", "RenderProgress", "Kernel", "PathTracer", "WfptError", "workgroup_size_64",
-           "RNG_DISPATCH", "RNG_PIXEL", "FLAG_SPLIT_SHADE", "FLAG_NO_GRAPH", "STAGES", "lib", "build",
+           "RNG_DISPATCH", "RNG_PIXEL", "FLAG_SPLIT_SHADE", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "STAGES", "lib", "build",
            "tonemap_rgb8", "selftest_math", "device_count"]
 
 SPP = 10  # wavefront_common/src/parameters.rs:4
 SPF = 1   # wavefront_common/src/parameters.rs:5
 
 RNG_DISPATCH, RNG_PIXEL = 0, 1
-FLAG_SPLIT_SHADE, FLAG_NO_GRAPH = 1, 2
+FLAG_SPLIT_SHADE, FLAG_NO_GRAPH, FLAG_UNFUSED = 1, 2, 4
 INACTIVE_PIXEL = 0xFFFFFFFF
 # kernel.rs:32 loads shaders/{name}.wgsl; these are the stage names (path_tracer.rs:162,167,175,180,185)
 STAGES = {"generate_rays": 0, "extend": 1, "shade": 2, "miss_kernel": 3, "accumulate": 4,
-          "shade_lambertian": 5, "shade_metal": 6, "shade_dielectric": 7, "scan": 8}
-STAGE_COUNT = 9
+          "shade_lambertian": 5, "shade_metal": 6, "shade_dielectric": 7, "scan": 8,
+          # fused launches of the device-resident loop (timing only; not dispatchable through Kernel)
+          "bounce_first": 9, "bounce": 10, "bounce_last": 11}
+STAGE_COUNT = 12
 
 SPHERE = np.dtype([("center", "<f4", 4), ("radius", "<f4"), ("material_idx", "<u4"),
                    ("material_type", "<u4"), ("_buffer", "<u4")])
@@ -162,6 +164,8 @@ def lib():
         "wfpt_write_rays": (i32, [vp, vp, u32]),
         "wfpt_read_bounce_table": (i32, [vp, vp, u32, C.POINTER(u32)]),
         "wfpt_read_totals": (i32, [vp, vp]),
+        "wfpt_read_wavefront_totals": (i32, [vp, vp, u32, C.POINTER(u32)]),
+        "wfpt_device_info": (i32, [i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]),
         "wfpt_tonemap_rgb8": (None, [vp, u32, u32, vp]),
         "wfpt_selftest_math": (i32, [i32, i32, vp, vp, vp, sz]),
         "wfpt_build_info": (C.c_char_p, []),
@@ -195,6 +199,16 @@ def _p(a):
 
 def device_count():
     return lib().wfpt_device_count()
+
+
+def device_info(device=0):
+    """CU count, memory clock (kHz), memory bus width (bits), memory bytes of HIP device `device`."""
+    cu, clk, width, mem = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    st = lib().wfpt_device_info(device, C.byref(cu), C.byref(clk), C.byref(width), C.byref(mem))
+    if st != 0:
+        raise WfptError(st, lib().wfpt_last_error(None).decode())
+    return {"compute_units": cu.value, "memory_clock_khz": clk.value, "memory_bus_width_bits": width.value,
+            "total_memory_bytes": mem.value}
 
 
 def workgroup_size_64(x):
@@ -511,7 +525,7 @@ class Kernel:
 
     def __init__(self, name, path_tracer):
         stage = lib().wfpt_stage_from_name(name.encode())
-        if stage < 0 or name == "scan":
+        if stage < 0 or stage >= STAGES["scan"]:
             # kernel.rs:36 unwraps the shader read and panics on an unknown name
             raise WfptError(-1, f"no such kernel stage: {name!r}")
         self.name, self.stage, self._pt = name, stage, path_tracer
@@ -767,6 +781,13 @@ class PathTracer:
         t = np.zeros(3, "<u8")
         self._check(lib().wfpt_read_totals(self.handle, _p(t)))
         return t
+
+    def wavefront_totals(self):
+        """(rays traced, hits, misses) per wavefront, summed over every sample rendered by the device-resident loop."""
+        t = np.zeros((64, 3), "<u8")
+        n = C.c_uint32()
+        self._check(lib().wfpt_read_wavefront_totals(self.handle, _p(t), 64, C.byref(n)))
+        return t[:n.value].copy()
 
 
 def shirley_path_tracer(width, height, seed=1, **kw):

@@ -57,6 +57,14 @@ struct wfpt_ctx {
     uint32_t *chunk_hits = nullptr, *chunk_miss = nullptr, *chunk_hit_base = nullptr, *chunk_miss_base = nullptr;
     uint16_t *mat_list = nullptr; // [3][batch][capacity] per-material hit lists
     uint32_t *chunk_mat = nullptr; // [3][batch][segments]
+    // fused bounce path (default device-resident loop): path records and miss payloads ping-pong between wavefronts
+    float4 *rec_mem[2] = {nullptr, nullptr};   // [batch][capacity][2]
+    uint32_t *f_miss_mem[2] = {nullptr, nullptr};
+    MissQueue f_mq[2]{};
+    uint32_t *f_chunk_hits[2] = {nullptr, nullptr}, *f_chunk_miss[2] = {nullptr, nullptr}, *first_seg = nullptr;
+    uint32_t classic_batch = 1; // slices of the stage-by-stage queues: batch_max when the loop runs unfused, else 1 (stage API)
+    uint32_t bounce_blocks_per_cu = 1;
+    bool fused = true;
     float *image = nullptr, *accumulated = nullptr;
     Control *ctl = nullptr;
     CameraDev *camera = nullptr;
@@ -198,8 +206,8 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.partition = partition ? 1u : 0u;
     a.mat_list = c->mat_list;
     a.chunk_mat = c->chunk_mat;
-    a.mat_list_mstride = static_cast<size_t>(c->batch_max) * c->capacity;
-    a.chunk_mat_mstride = static_cast<size_t>(c->batch_max) * c->n_chunks_max;
+    a.mat_list_mstride = static_cast<size_t>(c->classic_batch) * c->capacity;
+    a.chunk_mat_mstride = static_cast<size_t>(c->classic_batch) * c->n_chunks_max;
     a.q = c->q[qi];
     a.hq = c->hq;
     a.mq = c->mq;
@@ -212,10 +220,15 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.scene = c->scene;
     return a;
 }
-ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce, uint32_t nb = 1) {
+ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce, uint32_t nb = 1, int fused_parity = -1) {
     ScanArgs a{};
     a.batch = batch_of(c, nb);
     a.chunk_hits = c->chunk_hits; a.chunk_miss = c->chunk_miss;
+    if (fused_parity >= 0) { // counts written by the fused bounce kernel of this wavefront
+        a.chunk_hits = c->f_chunk_hits[fused_parity];
+        a.chunk_miss = c->f_chunk_miss[fused_parity];
+        a.first_seg = c->first_seg;
+    }
     a.chunk_hit_base = c->chunk_hit_base; a.chunk_miss_base = c->chunk_miss_base;
     a.ctl = c->ctl;
     a.n_in = n_in;
@@ -232,8 +245,8 @@ ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit
     a.split = (material != 0xffffffffu || (c->p.flags & WFPT_FLAG_SPLIT_SHADE)) ? 1u : 0u;
     a.mat_list = c->mat_list;
     a.chunk_mat = c->chunk_mat;
-    a.mat_list_mstride = static_cast<size_t>(c->batch_max) * c->capacity;
-    a.chunk_mat_mstride = static_cast<size_t>(c->batch_max) * c->n_chunks_max;
+    a.mat_list_mstride = static_cast<size_t>(c->classic_batch) * c->capacity;
+    a.chunk_mat_mstride = static_cast<size_t>(c->classic_batch) * c->n_chunks_max;
     a.q = c->q[qi];
     a.ext = c->q[qi ^ 1];
     a.hq = c->hq;
@@ -276,6 +289,37 @@ AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping,
     return a;
 }
 
+BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb) {
+    BounceArgs a{};
+    a.batch = batch_of(c, nb);
+    a.rec_in = c->rec_mem[in_parity];
+    a.rec_out = c->rec_mem[out_parity];
+    a.in_hits = c->f_chunk_hits[in_parity];
+    a.in_miss = c->f_chunk_miss[in_parity];
+    a.in_hit_base = c->chunk_hit_base;
+    a.in_first_seg = c->first_seg;
+    a.out_hits = c->f_chunk_hits[out_parity];
+    a.out_miss = c->f_chunk_miss[out_parity];
+    a.mq_in = c->f_mq[in_parity];
+    a.mq_out = c->f_mq[out_parity];
+    a.image = c->image;
+    a.ctl = c->ctl;
+    a.camera = c->camera;
+    a.gx = c->tiles_x;
+    a.gy = c->tiles_y_local;
+    a.capacity = c->capacity;
+    a.rng_mode = c->p.rng_mode;
+    a.image_width = c->width;
+    a.tile = c->tile;
+    a.scene = c->scene;
+    return a;
+}
+uint32_t bounce_grid(const wfpt_ctx *c, uint32_t n) {
+    // hit items + miss items never exceed 1.25 work items per segment
+    const uint64_t items = (static_cast<uint64_t>(c->n_chunks_max) * 5u / 4u + 1u) * n;
+    return static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->bounce_blocks_per_cu));
+}
+
 // One fused sample on the stream (pt:291-368). `ev`: optional (stage, start, stop) event recorder.
 struct EventRec { int stage; hipEvent_t start, stop; };
 int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
@@ -302,6 +346,24 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     };
     c->cur = 0;
     const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
+    if (c->fused) {
+        // generate+extend | scan | (shade+extend+miss | scan) x (max_wavefronts - 1) | shade+miss | accumulate
+        const uint32_t grid = bounce_grid(c, nb);
+        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_bounce(bounce_args(c, 1, 0, nb), kBounceFirst, grid, c->stream); }));
+        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+            const int par = static_cast<int>(b & 1u);
+            WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
+                              [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par), c->stream); }));
+            if (b + 1 < c->p.max_wavefronts)
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceMiddle, grid, c->stream); }));
+            else
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceLast, grid, c->stream); }));
+        }
+        WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
+                     return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
+                 }));
+        return WFPT_OK;
+    }
     WFPT_HIP(c, timed(WFPT_STAGE_GENERATE_RAYS,
                       [&] { return launch_generate(generate_args(c, c->tiles_x, c->tiles_y_local, true, nb), c->stream); }));
     for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
@@ -444,7 +506,7 @@ extern "C" {
 
 const char *wfpt_build_info(void) {
     static const std::string info = std::string("arch=gfx950;chunk=") + std::to_string(kChunk) +
-                                    ";extend_threads=" + std::to_string(kExtendThreads) + ";max_batch=" + std::to_string(kMaxBatch) + ";fp=ieee-no-contract";
+                                    ";extend_threads=" + std::to_string(kExtendThreads) + ";max_batch=" + std::to_string(kMaxBatch) + ";loop=fused-bounce;fp=ieee-no-contract";
     return info.c_str();
 }
 
@@ -525,7 +587,10 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     c->capacity = static_cast<uint32_t>(cap);
     c->n_chunks_max = c->capacity / kChunk;
     c->batch_max = params->batch == 0 ? 16u : std::min<uint32_t>(params->batch, kMaxBatch);
-    const size_t nb = c->batch_max;
+    c->fused = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE)) == 0;
+    c->classic_batch = c->fused ? 1u : c->batch_max; // the stage API works on slice 0 only
+    const size_t nb_all = c->batch_max;
+    const size_t nb = c->classic_batch;
 
     for (int k = 0; k < 2; ++k) {
         CREATE_HIP(dmalloc(&c->ray_mem[k], nb * 7 * static_cast<size_t>(c->capacity)));
@@ -536,7 +601,7 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(dmalloc(&c->miss_mem, 3 * nb * c->capacity));
     c->hq = {c->hit_mem, nb * c->capacity};
     c->mq = {c->miss_mem, nb * c->capacity};
-    const size_t n_counts = nb * c->n_chunks_max;
+    const size_t n_counts = nb_all * c->n_chunks_max; // the scan's bases serve both paths
     CREATE_HIP(dmalloc(&c->chunk_hits, n_counts));
     CREATE_HIP(dmalloc(&c->chunk_miss, n_counts));
     CREATE_HIP(dmalloc(&c->chunk_hit_base, n_counts));
@@ -549,9 +614,23 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(dmalloc(&c->chunk_mat, 3 * n_counts));
     CREATE_HIP(hipMemsetAsync(c->chunk_mat, 0, sizeof(uint32_t) * 3 * n_counts, c->stream));
     c->image_floats = (3 * static_cast<size_t>(c->pixel_capacity) + 7) / 4 * 4; // slices stay 16-byte aligned
-    CREATE_HIP(dmalloc(&c->image, nb * c->image_floats));
+    CREATE_HIP(dmalloc(&c->image, nb_all * c->image_floats));
     CREATE_HIP(dmalloc(&c->accumulated, c->image_floats));
-    CREATE_HIP(launch_fill(c->image, 1.0f, nb * c->image_floats, c->stream));                        // pt:53-58
+    CREATE_HIP(launch_fill(c->image, 1.0f, nb_all * c->image_floats, c->stream));                        // pt:53-58
+    if (c->fused) {
+        const size_t slots = nb_all * c->capacity, counts = nb_all * c->n_chunks_max;
+        for (int k = 0; k < 2; ++k) {
+            CREATE_HIP(dmalloc(&c->rec_mem[k], 2 * slots));
+            CREATE_HIP(dmalloc(&c->f_miss_mem[k], 3 * slots));
+            c->f_mq[k] = {c->f_miss_mem[k], slots};
+            CREATE_HIP(dmalloc(&c->f_chunk_hits[k], counts));
+            CREATE_HIP(dmalloc(&c->f_chunk_miss[k], counts));
+            CREATE_HIP(hipMemsetAsync(c->f_chunk_hits[k], 0, sizeof(uint32_t) * counts, c->stream));
+            CREATE_HIP(hipMemsetAsync(c->f_chunk_miss[k], 0, sizeof(uint32_t) * counts, c->stream));
+        }
+        CREATE_HIP(dmalloc(&c->first_seg, counts));
+        CREATE_HIP(hipMemsetAsync(c->first_seg, 0, sizeof(uint32_t) * counts, c->stream));
+    }
     CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->image_floats, c->stream));       // pt:60-65
     CREATE_HIP(dmalloc(&c->ctl, kMaxBatch));
     CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control) * kMaxBatch, c->stream));
@@ -647,6 +726,9 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     const uint32_t cus = static_cast<uint32_t>(prop.multiProcessorCount);
     c->cus = cus;
     c->blocks_per_cu = static_cast<uint32_t>(blocks_per_cu);
+    int bounce_blocks = 1;
+    CREATE_HIP(bounce_blocks_per_cu(c->scene, &bounce_blocks));
+    c->bounce_blocks_per_cu = static_cast<uint32_t>(std::max(bounce_blocks, 1));
     c->accumulate_grid = std::min<uint32_t>((3u * c->pixel_capacity / 4u + 255u) / 256u, cus * 8u);
     if (c->accumulate_grid == 0) c->accumulate_grid = 1;
     CREATE_HIP(hipStreamSynchronize(c->stream));
@@ -684,7 +766,9 @@ void wfpt_destroy(wfpt_ctx *c) {
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
-    void *bufs[] = {c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->d_shade_rec, c->chunk_hits,
+    void *bufs[] = {c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
+                    c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg,
+                    c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->d_shade_rec, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera,
                     c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,
@@ -1022,6 +1106,33 @@ int wfpt_read_totals(wfpt_ctx *c, uint64_t totals[3]) {
     Control ctl;
     WFPT_HIP(c, hipMemcpy(&ctl, c->ctl, sizeof ctl, hipMemcpyDeviceToHost));
     for (int k = 0; k < 3; ++k) totals[k] = ctl.totals[k];
+    return WFPT_OK;
+}
+
+int wfpt_read_wavefront_totals(wfpt_ctx *c, uint64_t *rows3, uint32_t max_rows, uint32_t *n_rows) {
+    if (!c || !rows3 || !n_rows) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_wavefront_totals: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    Control ctl;
+    WFPT_HIP(c, hipMemcpy(&ctl, c->ctl, sizeof ctl, hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < static_cast<uint32_t>(kMaxRows) && b < c->p.max_wavefronts && n < max_rows; ++b, ++n)
+        for (int k = 0; k < 3; ++k) rows3[3 * n + k] = ctl.wave_totals[b][k];
+    *n_rows = n;
+    return WFPT_OK;
+}
+
+int wfpt_device_info(int device, uint32_t *compute_units, uint32_t *memory_clock_khz, uint32_t *memory_bus_width_bits,
+                     uint64_t *total_memory_bytes) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return fail(nullptr, WFPT_ERR_NO_DEVICE, "wfpt_device_info: no such HIP device");
+    hipDeviceProp_t prop;
+    WFPT_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (compute_units) *compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
+    if (memory_clock_khz) *memory_clock_khz = static_cast<uint32_t>(prop.memoryClockRate);
+    if (memory_bus_width_bits) *memory_bus_width_bits = static_cast<uint32_t>(prop.memoryBusWidth);
+    if (total_memory_bytes) *total_memory_bytes = static_cast<uint64_t>(prop.totalGlobalMem);
     return WFPT_OK;
 }
 

@@ -245,7 +245,7 @@ template <typename Prims> class BvhBuilder {
 
 const char *const kStageNames[WFPT_STAGE_COUNT] = {"generate_rays",    "extend",      "shade",           "miss_kernel",
                                                    "accumulate",       "shade_lambertian", "shade_metal", "shade_dielectric",
-                                                   "scan"};
+                                                   "scan",             "bounce_first", "bounce",          "bounce_last"};
 
 } // namespace
 

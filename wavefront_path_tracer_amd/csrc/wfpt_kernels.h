@@ -76,6 +76,7 @@ struct Control {
     uint32_t _pad;
     uint32_t rows[kMaxRows][4]; // (rays_in, hits, misses, shaded) per bounce of the current sample
     unsigned long long totals[4]; // rays traced, hits, misses, samples
+    unsigned long long wave_totals[kMaxRows][3]; // per wavefront, over all fused samples: rays traced, hits, misses
 };
 
 // What shade needs to know about a primitive, merged into one 48-byte record (three float4) so that one
@@ -170,9 +171,38 @@ struct ScanArgs {
     Control *ctl;
     const uint32_t *n_in;
     uint32_t limit;
+    uint32_t *first_seg; // fused bounce kernel: first_seg[s] = segment that holds hit 512*s (may be null)
     uint32_t fused;      // 1: drive the device-resident loop; 0: stage API (counters protocol only)
     uint32_t miss_floor;
     uint32_t bounce;
+};
+
+// ---- fused bounce kernel of the device-resident loop (DESIGN.md "The loop"): one launch per wavefront does
+//   shade(hit of wavefront b-1) -> extend(the extension ray, straight from registers) -> compaction,
+// plus miss_kernel for wavefront b-1's misses. The wavefront's queue IS the hit queue: a *path record* is the hit
+// (point, incoming direction, primitive, pixel), 32 B as two float4, segment-compacted like the hit queue.
+constexpr int kBounceFirst = 0;  // generate_rays -> extend                 (wavefront 0)
+constexpr int kBounceMiddle = 1; // shade -> extend, miss_kernel            (wavefronts 1 .. max-1)
+constexpr int kBounceLast = 2;   // shade (throughput only), miss_kernel    (after the last extend)
+constexpr int kMissSegsPerItem = 4; // miss work item = this many input segments
+
+struct BounceArgs {
+    Batch batch;
+    const float4 *rec_in;   // [batch][capacity][2]: (p.xyz | pixel), (d.xyz | prim) of the previous wavefront's hits
+    float4 *rec_out;
+    const uint32_t *in_hits, *in_hit_base, *in_miss; // per-segment counts / bases of the previous wavefront (scan's output)
+    const uint32_t *in_first_seg;                    // segment holding hit 512*s, per output segment s (scan's output)
+    uint32_t *out_hits, *out_miss;                   // per-segment counts of this wavefront
+    MissQueue mq_in, mq_out;                         // (dy, pixel) payload of the misses; the ridx plane is unused here
+    float *image;
+    Control *ctl;
+    const CameraDev *camera;
+    uint32_t gx, gy;       // first wavefront: tiles of this context (gy counts this rank's bands)
+    uint32_t capacity;
+    uint32_t rng_mode;
+    uint32_t image_width;
+    Tiling tile;
+    SceneDev scene;
 };
 
 struct ShadeArgs {
@@ -222,6 +252,9 @@ struct AccumulateArgs {
 hipError_t launch_generate(const GenerateArgs &a, hipStream_t s);
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s); // one workgroup per sample
+hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s);
+hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks);
+uint32_t bounce_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene);
 hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);

@@ -67,6 +67,41 @@ __device__ __forceinline__ float3_ rng_next_in_unit_sphere(uint32_t &state) {
     return {r * sin_theta * c, r * sin_theta * s, r * cos_theta};
 }
 
+// gr:60-88 for one pixel: jittered NDC -> far-plane point -> thin-lens origin -> normalised world direction.
+// Shared by generate_rays_kernel and the fused first bounce so that both produce the same bits.
+struct PrimaryRay { float ox, oy, oz, dx, dy, dz; };
+__device__ __forceinline__ PrimaryRay primary_ray(const CameraDev &cam, uint32_t id_x, uint32_t id_y, uint32_t width,
+                                                  uint32_t height, wfpt_frame_buffer fb) {
+    uint32_t rng = init_rng(id_x, id_y, width, fb.frame); // gr:60
+    rng = advance(rng, fb.sample_number * 10u);           // gr:61
+    float off_x, off_y;
+    rng_next_in_unit_disk(rng, off_x, off_y);             // gr:63
+
+    float ndc_x = (static_cast<float>(id_x) + off_x) / static_cast<float>(width); // gr:66
+    float ndc_y = 1.0f - (static_cast<float>(id_y) + off_y) / static_cast<float>(height);
+    ndc_x = 2.0f * ndc_x - 1.0f; // gr:67
+    ndc_y = 2.0f * ndc_y - 1.0f;
+    float4_ pp = mat_mul(cam.inv_proj, {ndc_x, ndc_y, 1.0f, 1.0f}); // gr:68
+    const float pw = pp.w;
+    pp = {pp.x / pw, pp.y / pw, pp.z / pw, pp.w / pw}; // gr:69
+
+    float4_ origin = {cam.cam.position[0], cam.cam.position[1], cam.cam.position[2], cam.cam.position[3]};
+    if (cam.cam.defocus_radius > 0.0f) { // gr:73-82
+        rng_next_in_unit_disk(rng, off_x, off_y);
+        const float R = cam.cam.defocus_radius;
+        const float4_ p_lens = {R * off_x, R * off_y, R * 0.0f, 1.0f};
+        float4_ lo = mat_mul(cam.view, p_lens);
+        const float lw = lo.w;
+        origin = {lo.x / lw, lo.y / lw, lo.z / lw, lo.w / lw};
+        const float tf = cam.cam.focus_distance / pp.z;
+        pp = {tf * pp.x - p_lens.x, tf * pp.y - p_lens.y, tf * pp.z - p_lens.z, tf * pp.w - p_lens.w};
+    }
+    const float4_ rd = mat_mul(cam.view, {pp.x, pp.y, pp.z, 0.0f}); // gr:84
+    // normalize(vec4) (gr:86): length = sqrt(((x*x + y*y) + z*z) + w*w)
+    const float len = sqrt_(((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z) + rd.w * rd.w);
+    return {origin.x, origin.y, origin.z, rd.x / len, rd.y / len, rd.z / len};
+}
+
 // ================================================================================================
 // generate_rays (gr:42-91): one thread per queue slot, slot = tile*64 + local (8x8-tile order), so a
 // wave is one 8x8 pixel tile and the SoA stores are fully coalesced.
@@ -95,37 +130,10 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
         return;
     }
     const uint32_t pixel_idx = id_x + id_y * width; // gr:57
-    uint32_t rng = init_rng(id_x, id_y, width, fb.frame); // gr:60
-    rng = advance(rng, fb.sample_number * 10u);           // gr:61
-    float off_x, off_y;
-    rng_next_in_unit_disk(rng, off_x, off_y);             // gr:63
+    const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, width, height, fb);
 
-    float ndc_x = (static_cast<float>(id_x) + off_x) / static_cast<float>(width); // gr:66
-    float ndc_y = 1.0f - (static_cast<float>(id_y) + off_y) / static_cast<float>(height);
-    ndc_x = 2.0f * ndc_x - 1.0f; // gr:67
-    ndc_y = 2.0f * ndc_y - 1.0f;
-    const CameraDev &cam = *a.camera;
-    float4_ pp = mat_mul(cam.inv_proj, {ndc_x, ndc_y, 1.0f, 1.0f}); // gr:68
-    const float pw = pp.w;
-    pp = {pp.x / pw, pp.y / pw, pp.z / pw, pp.w / pw}; // gr:69
-
-    float4_ origin = {cam.cam.position[0], cam.cam.position[1], cam.cam.position[2], cam.cam.position[3]};
-    if (cam.cam.defocus_radius > 0.0f) { // gr:73-82
-        rng_next_in_unit_disk(rng, off_x, off_y);
-        const float R = cam.cam.defocus_radius;
-        const float4_ p_lens = {R * off_x, R * off_y, R * 0.0f, 1.0f};
-        float4_ lo = mat_mul(cam.view, p_lens);
-        const float lw = lo.w;
-        origin = {lo.x / lw, lo.y / lw, lo.z / lw, lo.w / lw};
-        const float tf = cam.cam.focus_distance / pp.z;
-        pp = {tf * pp.x - p_lens.x, tf * pp.y - p_lens.y, tf * pp.z - p_lens.z, tf * pp.w - p_lens.w};
-    }
-    const float4_ rd = mat_mul(cam.view, {pp.x, pp.y, pp.z, 0.0f}); // gr:84
-    // normalize(vec4) (gr:86): length = sqrt(((x*x + y*y) + z*z) + w*w)
-    const float len = sqrt_(((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z) + rd.w * rd.w);
-
-    a.q.ox()[idx] = origin.x; a.q.oy()[idx] = origin.y; a.q.oz()[idx] = origin.z;
-    a.q.dx()[idx] = rd.x / len; a.q.dy()[idx] = rd.y / len; a.q.dz()[idx] = rd.z / len;
+    a.q.ox()[idx] = pr.ox; a.q.oy()[idx] = pr.oy; a.q.oz()[idx] = pr.oz;
+    a.q.dx()[idx] = pr.dx; a.q.dy()[idx] = pr.dy; a.q.dz()[idx] = pr.dz;
     a.q.pixel()[idx] = pixel_idx;
     if (a.reset_image) { // pt:305-306 folded in: throughput starts at 1
         const uint32_t lp = local_pixel(pixel_idx, width, a.tile);
@@ -509,6 +517,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     a.chunk_miss += sample * a.batch.chunk_stride;
     a.chunk_hit_base += sample * a.batch.chunk_stride;
     a.chunk_miss_base += sample * a.batch.chunk_stride;
+    if (a.first_seg) a.first_seg += sample * a.batch.chunk_stride;
     const uint32_t n = umin(a.n_in[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit);
     const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -530,8 +539,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
             tile_m += m;
         }
         if (i < n_chunks) {
-            a.chunk_hit_base[i] = carry_h + before_h + ih - vh;
+            const uint32_t base_h = carry_h + before_h + ih - vh;
+            a.chunk_hit_base[i] = base_h;
             a.chunk_miss_base[i] = carry_m + before_m + im - vm;
+            // the fused bounce kernel cuts the hit queue into runs of kChunk consecutive hits: remember which segment
+            // holds the first hit of each run (a segment holds at most kChunk hits, so at most one multiple of kChunk)
+            if (a.first_seg && vh > 0) {
+                const uint32_t m = (base_h + kChunk - 1) / kChunk;
+                if (m * kChunk < base_h + vh) a.first_seg[m] = i;
+            }
         }
         carry_h += tile_h;
         carry_m += tile_m;
@@ -602,6 +618,70 @@ __device__ __forceinline__ float3_ reflect(float3_ r, float3_ n) { // sh:164-166
     return {r.x - k * n.x, r.y - k * n.y, r.z - k * n.z};
 }
 
+// sh:71-73: shade's RNG state for hit `h` of a dispatch whose x extent is `gx` workgroups (keyed by the dispatch's
+// global_invocation_id), or keyed by the ray's own pixel (WFPT_RNG_PIXEL).
+__device__ __forceinline__ uint32_t shade_rng(uint32_t rng_mode, uint32_t h, uint32_t gx, uint32_t pixel_idx, wfpt_frame_buffer fb) {
+    uint32_t id_x, id_y;
+    if (rng_mode == WFPT_RNG_PIXEL) {
+        id_y = pixel_idx / fb.width;
+        id_x = pixel_idx - id_y * fb.width;
+    } else {
+        const uint32_t wg = h >> 6, li = h & 63u;
+        const uint32_t wgy = wg / gx;
+        id_x = (wg - wgy * gx) * 8u + (li & 7u);
+        id_y = wgy * 8u + (li >> 3);
+    }
+    const uint32_t rng = init_rng(id_x, id_y, fb.width, fb.frame);
+    return advance(rng, fb.sample_number * 10u);
+}
+
+// sh:93-151: the extension direction of one hit at point p of primitive record (rec0 = centre | normal, fuzz;
+// rec1 = albedo, refraction index) for the incoming direction rdir (not normalised after bounce 0). Shared by
+// shade_kernel and the fused bounce kernel so that both produce the same bits.
+__device__ __forceinline__ float3_ scatter(uint32_t rng, float3_ p, float3_ rdir, float4 rec0, float4 rec1, uint32_t mat_type,
+                                           uint32_t prim_kind) {
+    const float fuzz = rec0.w, refract_index = rec1.w;
+    // spheres: always-outward normal (sh:93); triangles: normalize(cross(e1, e2)), never flipped
+    const float3_ nrm = prim_kind == 0 ? normalize3({p.x - rec0.x, p.y - rec0.y, p.z - rec0.z}) : float3_{rec0.x, rec0.y, rec0.z};
+    float3_ ext;
+    if (mat_type == 1u) { // sh:110-114 metal
+        const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
+        const float3_ rf = reflect(rdir, nrm);
+        ext = {rf.x + fuzz * rb.x, rf.y + fuzz * rb.y, rf.z + fuzz * rb.z};
+    } else if (mat_type == 2u) { // sh:115-151 dielectric
+        float3_ norm = nrm;
+        const float3_ uv = normalize3(rdir);
+        float cos_theta = min_(dot3(norm, {-uv.x, -uv.y, -uv.z}), 1.0f);
+        float eta;
+        if (cos_theta >= 0.0f) {
+            eta = 1.0f / refract_index;
+        } else {
+            eta = refract_index;
+            norm = {norm.x * -1.0f, norm.y * -1.0f, norm.z * -1.0f};
+            cos_theta = cos_theta * -1.0f;
+        }
+        const float reflectance = schlick(cos_theta, eta);
+        // refract(), sh:168-176
+        const float ct = dot3(uv, norm);
+        const float k = 1.0f - eta * eta * (1.0f - ct * ct);
+        if (k >= 0.0f) {
+            if (reflectance > rng_next_float(rng)) {
+                ext = reflect(uv, norm);
+            } else {
+                const float m = eta * ct + sqrt_(k);
+                ext = {eta * uv.x - m * norm.x, eta * uv.y - m * norm.y, eta * uv.z - m * norm.z};
+            }
+        } else {
+            ext = reflect(uv, norm);
+        }
+    } else { // sh:102-109 lambertian (case 0u, default)
+        const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
+        ext = {nrm.x + rb.x, nrm.y + rb.y, nrm.z + rb.z};
+        if (sqrt_(dot3(ext, ext)) < 0.001f) ext = nrm;
+    }
+    return ext;
+}
+
 // Walks the hit-queue segments: segment c holds chunk_hits[c] hits compacted at its front, and
 // chunk_hit_base[c] is the queue position of its first hit, so the logical hit index (the thread index
 // of the reference's shade dispatch) is base + rank. Whole waves beyond a segment's count skip, so lanes
@@ -666,7 +746,6 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             const float4 rec0 = a.scene.shade_rec[3u * prim], rec1 = a.scene.shade_rec[3u * prim + 1u],
                          rec2 = a.scene.shade_rec[3u * prim + 2u];
             const uint32_t mat_type = __float_as_uint(rec2.x);
-            struct { float albedo[3]; float fuzz, refract_index; } mat = {{rec1.x, rec1.y, rec1.z}, rec0.w, rec1.w};
             const float ox = a.q.ox()[ridx], oy = a.q.oy()[ridx], oz = a.q.oz()[ridx];
             const float dx = a.q.dx()[ridx], dy = a.q.dy()[ridx], dz = a.q.dz()[ridx];
             const uint32_t pixel_idx = a.q.pixel()[ridx];
@@ -675,69 +754,17 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             float *px = a.image + 3u * static_cast<size_t>(lp);
             const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
 
-            // sh:71-73: RNG keyed by the dispatch's global_invocation_id (or by the pixel)
-            uint32_t id_x, id_y;
-            if (a.rng_mode == WFPT_RNG_PIXEL) {
-                id_y = pixel_idx / fb.width;
-                id_x = pixel_idx - id_y * fb.width;
-            } else {
-                const uint32_t wg = h >> 6, li = h & 63u;
-                const uint32_t wgy = wg / gx;
-                id_x = (wg - wgy * gx) * 8u + (li & 7u);
-                id_y = wgy * 8u + (li >> 3);
-            }
-            uint32_t rng = init_rng(id_x, id_y, fb.width, fb.frame);
-            rng = advance(rng, fb.sample_number * 10u);
-
+            const uint32_t rng = shade_rng(a.rng_mode, h, gx, pixel_idx, fb);
             // sh:91-93
             const float p_x = ox + t * dx, p_y = oy + t * dy, p_z = oz + t * dz;
-            // spheres: always-outward normal (sh:93); triangles: normalize(cross(e1, e2)), never flipped
-            const float3_ nrm = a.scene.prim_kind == 0 ? normalize3({p_x - rec0.x, p_y - rec0.y, p_z - rec0.z})
-                                                       : float3_{rec0.x, rec0.y, rec0.z};
-            const float3_ rdir = {dx, dy, dz};
-            float3_ ext;
-            if (mat_type == 1u) { // sh:110-114 metal
-                const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
-                const float3_ rf = reflect(rdir, nrm);
-                ext = {rf.x + mat.fuzz * rb.x, rf.y + mat.fuzz * rb.y, rf.z + mat.fuzz * rb.z};
-            } else if (mat_type == 2u) { // sh:115-151 dielectric
-                float3_ norm = nrm;
-                const float3_ uv = normalize3(rdir);
-                float cos_theta = min_(dot3(norm, {-uv.x, -uv.y, -uv.z}), 1.0f);
-                float eta;
-                if (cos_theta >= 0.0f) {
-                    eta = 1.0f / mat.refract_index;
-                } else {
-                    eta = mat.refract_index;
-                    norm = {norm.x * -1.0f, norm.y * -1.0f, norm.z * -1.0f};
-                    cos_theta = cos_theta * -1.0f;
-                }
-                const float reflectance = schlick(cos_theta, eta);
-                // refract(), sh:168-176
-                const float ct = dot3(uv, norm);
-                const float k = 1.0f - eta * eta * (1.0f - ct * ct);
-                if (k >= 0.0f) {
-                    if (reflectance > rng_next_float(rng)) {
-                        ext = reflect(uv, norm);
-                    } else {
-                        const float m = eta * ct + sqrt_(k);
-                        ext = {eta * uv.x - m * norm.x, eta * uv.y - m * norm.y, eta * uv.z - m * norm.z};
-                    }
-                } else {
-                    ext = reflect(uv, norm);
-                }
-            } else { // sh:102-109 lambertian (case 0u, default)
-                const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
-                ext = {nrm.x + rb.x, nrm.y + rb.y, nrm.z + rb.z};
-                if (sqrt_(dot3(ext, ext)) < 0.001f) ext = nrm;
-            }
+            const float3_ ext = scatter(rng, {p_x, p_y, p_z}, {dx, dy, dz}, rec0, rec1, mat_type, a.scene.prim_kind);
             // sh:153-155: direction is NOT normalised; invDirection is recomputed by extend
             a.ext.ox()[h] = p_x; a.ext.oy()[h] = p_y; a.ext.oz()[h] = p_z;
             a.ext.dx()[h] = ext.x; a.ext.dy()[h] = ext.y; a.ext.dz()[h] = ext.z;
             a.ext.pixel()[h] = pixel_idx;
-            px[0] = thr_r * mat.albedo[0];
-            px[1] = thr_g * mat.albedo[1];
-            px[2] = thr_b * mat.albedo[2];
+            px[0] = thr_r * rec1.x; // albedo
+            px[1] = thr_g * rec1.y;
+            px[2] = thr_b * rec1.z;
         }
     }
 }
@@ -788,6 +815,237 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
 }
 
 // ================================================================================================
+// Fused bounce kernel of the device-resident loop. The reference's loop runs, per wavefront, extend -> (host reads
+// the counters) -> shade -> miss_kernel -> copy extension rays back (pt:323-353). shade of wavefront b-1 and extend
+// of wavefront b touch the same path one after the other, so here ONE launch per wavefront takes a hit of
+// wavefront b-1, shades it (sh:56-156) and traces the extension ray straight from registers (ex:47-210): the
+// extension-ray queue, its 28 B/ray write and 28 B/ray read, and two launches per wavefront disappear, and the
+// latency-bound gathers of shade overlap with the VALU-bound traversal of the other waves. The queue between
+// wavefronts is the hit queue, carried as 32-byte path records (hit point | pixel, incoming direction | primitive):
+// shade streams them instead of gathering the ray through its index. miss_kernel (mk:13-38) of wavefront b-1 runs
+// as extra work items of the same launch (the loop-exit test of pt:332 sits between the two wavefronts, so a
+// wavefront's misses may only be applied once `scan` has decided that the loop goes on).
+//
+// Everything the reference's stages would compute is computed, in the same order per path, by the same device
+// functions (primary_ray, shade_rng, scatter, trace_ray): the images are bit-identical to the stage-by-stage chain.
+// shade's thread index h (its RNG key under WFPT_RNG_DISPATCH, sh:72) is the hit's position in the hit queue under
+// ascending-order atomics, exactly as in shade_kernel: base[segment] + rank.
+//
+// MODE kBounceFirst : work item = 512 ray slots of generate_rays' numbering (8 tiles): generate -> trace.
+//      kBounceMiddle: hit items = 512 consecutive hits h of the previous wavefront: shade -> trace; then miss items.
+//      kBounceLast  : after the last extend: shade only multiplies the throughput (sh:84-87); miss items.
+// ================================================================================================
+struct BounceLds {
+    uint32_t *cnt;     // [2][2][kExtendWaves] per-wave hit / miss counts, double-buffered by iteration parity
+    uint32_t *next;    // [2] next work item
+    uint32_t *n_hit;   // [kMaxBatch] hits to shade (first wavefront: ray slots) per sample
+    uint32_t *first_h; // [kMaxBatch + 1] first hit item of each sample
+    uint32_t *first_m; // [kMaxBatch + 1] first miss item of each sample
+    uint32_t *stack;   // HBM-resident scenes: [2 * kStackDepth][kExtendThreads]
+};
+constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + kMaxBatch + 2u * (kMaxBatch + 1u) + 4u; // +4: keeps `stack` 16-byte aligned
+
+template <int MODE, typename Trail, int PRIM, bool LDS_SCENE>
+__global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_kernel(BounceArgs a) {
+    extern __shared__ float4 lds[];
+    constexpr bool TRACE = MODE != kBounceLast;
+    constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u;
+    const bool stage_scene = TRACE && LDS_SCENE;
+    float4 *s_nodes = lds;
+    float4 *s_geom = lds + (stage_scene ? 2u * a.scene.n_nodes : 0u);
+    const uint32_t parent_words = stage_scene ? ((a.scene.n_nodes / 2u + 1u) + 7u) / 8u : 0u;
+    const uint32_t geom_words = stage_scene ? kGeomWords * a.scene.n_spheres : 0u;
+    uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_geom + geom_words);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_geom + geom_words + parent_words);
+    BounceLds L;
+    L.cnt = s_misc;
+    L.next = L.cnt + 4 * kExtendWaves;
+    L.n_hit = L.next + 2;
+    L.first_h = L.n_hit + kMaxBatch;
+    L.first_m = L.first_h + kMaxBatch + 1;
+    L.stack = s_misc + kBounceMiscWords;
+
+    const uint32_t n_slots = a.gx * a.gy * 64u; // first wavefront: ray slots of this context's tiles
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
+            const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
+            L.n_hit[smp] = n;
+            L.first_h[smp] = total;
+            total += (n + kChunk - 1) / kChunk;
+        }
+        L.first_h[a.batch.n] = total;
+        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
+            uint32_t segs = 0;
+            if (MODE != kBounceFirst && a.ctl[smp].miss_n > 0) segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
+            L.first_m[smp] = total;
+            total += (segs + kMissSegsPerItem - 1) / kMissSegsPerItem;
+        }
+        L.first_m[a.batch.n] = total;
+    }
+    __syncthreads();
+    const uint32_t n_hit_items = L.first_h[a.batch.n], n_items = L.first_m[a.batch.n];
+    if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n)
+        a.ctl[threadIdx.x].n_in = umin(n_slots, a.capacity); // pt:313-316: counter[2] = rays of the first wavefront (read by scan)
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
+    if (stage_scene) {
+        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_nodes[i];
+        for (uint32_t i = threadIdx.x; i < geom_words; i += kExtendThreads) s_geom[i] = a.scene.prim_geom[i];
+        const uint4 *g_par = reinterpret_cast<const uint4 *>(a.scene.pair_parent);
+        uint4 *s_par4 = reinterpret_cast<uint4 *>(s_parent);
+        for (uint32_t i = threadIdx.x; i < parent_words; i += kExtendThreads) s_par4[i] = g_par[i];
+        __syncthreads();
+    }
+    const wfpt_frame_buffer fb0 = a.ctl->frame;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t iter = 0;
+    while (item < n_items) {
+        const uint32_t buf = iter & 1u;
+        if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        if (item >= n_hit_items) {
+            // ---------------- miss_kernel (mk:13-38) for kMissSegsPerItem segments of the previous wavefront's miss queue
+            uint32_t smp = 0;
+            while (item >= L.first_m[smp + 1]) ++smp;
+            const uint32_t first_seg = (item - L.first_m[smp]) * kMissSegsPerItem;
+            const uint32_t n_segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
+            const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+            float *image = a.image + smp * a.batch.image_stride;
+            for (uint32_t k = 0; k < kMissSegsPerItem; ++k) {
+                const uint32_t seg = first_seg + k;
+                if (seg >= n_segs) break;
+                if (threadIdx.x < a.in_miss[co + seg]) {
+                    const size_t slot = qo + static_cast<size_t>(seg) * kChunk + threadIdx.x;
+                    const float dy = a.mq_in.dy()[slot]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
+                    const uint32_t pixel_idx = a.mq_in.pixel()[slot];
+                    const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
+                    const float om = 1.0f - t;
+                    const float cr = om * 1.0f + t * 0.5f; // mk:33
+                    const float cg = om * 1.0f + t * 0.7f;
+                    const float cb = om * 1.0f + t * 1.0f;
+                    float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
+                    px[0] *= cr; // mk:35-37
+                    px[1] *= cg;
+                    px[2] *= cb;
+                }
+            }
+            __syncthreads(); // L.next[buf] is visible
+            item = L.next[buf];
+            iter += 1;
+            continue;
+        }
+        uint32_t smp = 0;
+        while (item >= L.first_h[smp + 1]) ++smp; // block-uniform
+        const uint32_t seg_out = item - L.first_h[smp];
+        const uint32_t n = L.n_hit[smp];
+        const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+        float *image = a.image + smp * a.batch.image_stride;
+        wfpt_frame_buffer fb = fb0;
+        fb.frame += smp;
+
+        const uint32_t h = seg_out * kChunk + threadIdx.x; // first wavefront: generate_rays' slot index; else shade's thread index
+        bool live = h < n;
+        float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+        uint32_t pixel_idx = 0;
+        if (MODE == kBounceFirst) {
+            // ---------------- generate_rays (gr:42-91), true-size semantics: lanes outside the image emit nothing
+            const uint32_t workgroup_index = h >> 6, local_index = h & 63u;
+            const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
+            const uint32_t id_x = wx * 8u + (local_index & 7u);
+            const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
+            live = live && id_x < fb.width && id_y < fb.height;
+            if (live) {
+                pixel_idx = id_x + id_y * fb.width; // gr:57
+                const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
+                ox = pr.ox; oy = pr.oy; oz = pr.oz; dx = pr.dx; dy = pr.dy; dz = pr.dz;
+                float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, fb.width, a.tile));
+                px[0] = 1.0f; px[1] = 1.0f; px[2] = 1.0f; // pt:305-306 folded in: throughput starts at 1
+            }
+        } else if (live) {
+            // ---------------- shade (sh:56-156) of hit h of the previous wavefront
+            // its segment: the last one whose first hit is not after h, searched between the segments that hold the
+            // first hit of this run and of the next run (scan's first_seg table)
+            const uint32_t n_runs = (n + kChunk - 1) / kChunk;
+            uint32_t lo = a.in_first_seg[co + seg_out];
+            uint32_t hi = seg_out + 1 < n_runs ? a.in_first_seg[co + seg_out + 1] : (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk - 1u;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (a.in_hit_base[co + mid] <= h) lo = mid; else hi = mid - 1u;
+            }
+            const size_t slot = qo + static_cast<size_t>(lo) * kChunk + (h - a.in_hit_base[co + lo]);
+            const float4 ra = a.rec_in[2u * slot], rb = a.rec_in[2u * slot + 1u];
+            pixel_idx = __float_as_uint(ra.w);
+            const uint32_t prim = __float_as_uint(rb.w);
+            const float4 rec1 = a.scene.shade_rec[3u * prim + 1u];
+            // sh:84-87: throughput *= albedo, for every material type
+            float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
+            const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
+            if (TRACE) {
+                const float4 rec0 = a.scene.shade_rec[3u * prim], rec2 = a.scene.shade_rec[3u * prim + 2u];
+                const uint32_t rng = shade_rng(a.rng_mode, h, a.ctl[smp].shade_gx, pixel_idx, fb);
+                const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), a.scene.prim_kind);
+                ox = ra.x; oy = ra.y; oz = ra.z; // sh:153-155: the extension ray starts at the hit point, direction NOT normalised
+                dx = ext.x; dy = ext.y; dz = ext.z;
+            }
+            px[0] = thr_r * rec1.x;
+            px[1] = thr_g * rec1.y;
+            px[2] = thr_b * rec1.z;
+        }
+        if (!TRACE) {
+            __syncthreads();
+            item = L.next[buf];
+            iter += 1;
+            continue;
+        }
+        // ---------------- extend (ex:47-70) of the ray in registers
+        float t = 0.0f;
+        uint32_t prim = 0;
+        bool hit = false;
+        if (live) {
+            if (LDS_SCENE)
+                hit = trace_ray<Trail, PRIM, uint16_t, 0>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            else
+                hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
+                                                                     ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+        }
+        const bool miss = live && !hit;
+        const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
+        if (lane == 0) {
+            L.cnt[(buf * 2 + 0) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(hit_mask));
+            L.cnt[(buf * 2 + 1) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(miss_mask));
+        }
+        __syncthreads();
+        uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kExtendWaves; ++w) {
+            const uint32_t hc = L.cnt[(buf * 2 + 0) * kExtendWaves + w], mc = L.cnt[(buf * 2 + 1) * kExtendWaves + w];
+            hit_before += (w < wave) ? hc : 0u;
+            miss_before += (w < wave) ? mc : 0u;
+            hit_total += hc;
+            miss_total += mc;
+        }
+        const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
+        if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel
+            const size_t slot = seg + hit_before + mbcnt(hit_mask);
+            a.rec_out[2u * slot] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(pixel_idx));
+            a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
+        }
+        if (miss) { // what miss_kernel reads of the ray (mk:29-32)
+            const size_t slot = seg + miss_before + mbcnt(miss_mask);
+            a.mq_out.dy()[slot] = dy;
+            a.mq_out.pixel()[slot] = pixel_idx;
+        }
+        if (threadIdx.x == 0) {
+            a.out_hits[co + seg_out] = hit_total;
+            a.out_miss[co + seg_out] = miss_total;
+        }
+        item = L.next[buf];
+        iter += 1;
+    }
+}
+
+// ================================================================================================
 // accumulate (ac:4-17): pure streaming, 16 B per lane
 // ================================================================================================
 __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
@@ -820,10 +1078,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
                     c0->totals[0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
                     c0->totals[1] += c->rows[b][1];
                     c0->totals[2] += c->rows[b][2];
+                    c0->wave_totals[b][0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
+                    c0->wave_totals[b][1] += c->rows[b][1];
+                    c0->wave_totals[b][2] += c->rows[b][2];
                 }
             }
             c0->totals[3] += a.batch.n;
             c0->samples += a.batch.n;
+            c0->ticket = 0; // the fused loop's last bounce launch drew tickets after the last scan
             c0->frame.frame += a.batch.n; // RenderProgress::get_next_frame (parameters.rs:78-83) for the next samples
         }
     }
@@ -922,6 +1184,49 @@ hipError_t extend_blocks_per_cu(const SceneDev &scene, int *blocks) {
         }
     }
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, extend_variant(scene, false), kExtendThreads, scene.lds_bytes);
+}
+
+uint32_t bounce_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene) {
+    const uint32_t misc = 4u * kBounceMiscWords;
+    if (!lds_scene) return misc + 4u * 2u * kStackDepth * kExtendThreads;
+    const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
+    return 32u * n_nodes + 16u * (prim_kind == 0 ? 1u : 3u) * n_prims + 16u * parent_words + misc;
+}
+
+namespace {
+using BounceFn = void (*)(BounceArgs);
+template <int MODE, int PRIM> BounceFn bounce_pick(bool lds_scene, bool deep) {
+    if (!lds_scene) return bounce_kernel<MODE, unsigned long long, PRIM, false>;
+    return deep ? bounce_kernel<MODE, unsigned long long, PRIM, true> : bounce_kernel<MODE, uint32_t, PRIM, true>;
+}
+BounceFn bounce_variant(const SceneDev &sc, int mode) {
+    const bool lds = sc.lds_scene != 0, deep = sc.depth > 31u;
+    if (mode == kBounceLast) return bounce_kernel<kBounceLast, uint32_t, 0, false>; // no traversal: one variant
+    if (sc.prim_kind == 0) return mode == kBounceFirst ? bounce_pick<kBounceFirst, 0>(lds, deep) : bounce_pick<kBounceMiddle, 0>(lds, deep);
+    return mode == kBounceFirst ? bounce_pick<kBounceFirst, 1>(lds, deep) : bounce_pick<kBounceMiddle, 1>(lds, deep);
+}
+uint32_t bounce_dynamic_lds(const SceneDev &sc, int mode) {
+    return mode == kBounceLast ? 4u * kBounceMiscWords : bounce_lds_bytes(sc.n_nodes, sc.n_spheres, sc.prim_kind, sc.lds_scene != 0);
+}
+} // namespace
+
+hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks) {
+    hipError_t e = hipSuccess;
+    const uint32_t bytes = bounce_dynamic_lds(scene, kBounceMiddle);
+    if (bytes > 64u * 1024u) {
+        for (int mode : {kBounceFirst, kBounceMiddle}) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(bounce_variant(scene, mode)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, bounce_variant(scene, kBounceMiddle), kExtendThreads, bytes);
+}
+
+hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s) {
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(bounce_variant(a.scene, mode), dim3(grid), dim3(kExtendThreads), bounce_dynamic_lds(a.scene, mode), s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_generate(const GenerateArgs &a, hipStream_t s) {
