@@ -61,8 +61,8 @@ def parse():
                     help="CPU-baseline sample: whole samples per pixel of the same workload until this much time is spent")
     ap.add_argument("--no-stage-times", action="store_true")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
-                    help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only -- ranks may share one GPU, "
-                         "the gather goes through host memory")
+                    help="nccl = the frame is gathered by RCCL over xGMI through the C ABI (one GPU per rank). gloo: rehearsal "
+                         "only -- ranks may share one GPU, the gather goes through host memory")
     ap.add_argument("--dump", default=None, help="write the tone-mapped frame (PPM) here (rank 0)")
     return ap.parse_args()
 
@@ -143,16 +143,15 @@ def main():
     rehearsal = args.dist_backend == "gloo"
     gpu_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(gpu_index)
-    dev = torch.device("cuda", gpu_index)
     dist = None
     if world > 1:
+        # torch.distributed is the rendezvous and the control plane only (barrier, max of the timings, the 128-byte RCCL
+        # id): gloo on CPU tensors. The data plane -- the one gather of the frame -- is RCCL over xGMI behind the C ABI
+        # (wfpt_comm_init / wfpt_gather_accumulated), so a host without PyTorch shards exactly the same way.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    coll_dev = torch.device("cpu") if rehearsal else dev  # where collective tensors live
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    coll_dev = torch.device("cpu")  # where the control-plane tensors live
 
     mode_name = args.rng_mode if args.rng_mode != "auto" else ("dispatch" if world == 1 else "pixel")
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
@@ -177,14 +176,18 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if world > 1 and not rehearsal:
+        uid = [W.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        pt.comm_init(uid[0], rank, world)  # collective: ncclCommInitRank on every rank's own GPU
+
     def gather():
         if world == 1:
             return None
-        if rehearsal:
+        if rehearsal:  # ranks share a GPU, which RCCL refuses: slabs go through host memory (gloo)
             return tiles.gather_slabs(pt.accumulated(), rank, world, args.width, args.height)
-        # slabs go device -> device over xGMI and are de-interleaved on rank 0's GPU: no host copy in the timed region
-        return tiles.gather_slabs(pt.copy_accumulated_to_device, rank, world, args.width, args.height, device=dev,
-                                  keep_on_device=True)
+        pt.gather_accumulated()  # peers -> rank 0 over xGMI, de-interleaved on rank 0's GPU; asynchronous on the context's stream
+        return None
 
     pt.render(args.warmup)
     # prime (untimed) the captured launch shapes the timed K steps will replay: full batches + the remainder
@@ -213,6 +216,8 @@ def main():
         rays_total = rays
     if world == 1:
         frame = pt.accumulated()
+    elif not rehearsal and rank == 0:
+        frame = pt.gathered()  # outside the timed region: the frame crosses PCIe only for the dump / the check
 
     # ---- per-stage times and the roofline of the dominant kernel: same K steps again with hipEvent pairs around
     # every launch on the context's stream (a second pass, so the events do not perturb `value`)
@@ -275,7 +280,7 @@ def main():
                    "launch": "direct" if args.no_graph else "hipGraph",
                    "samples_in_flight": sorted({min(batch, args.steps), args.steps % batch} - {0}, reverse=True),
                    "parallelism": "single GPU" if world == 1 else
-                   f"pixel bands of 8 rows over {world} ranks + 1 gather ({'RCCL' if not rehearsal else 'gloo REHEARSAL, ranks share GPUs'})",
+                   f"pixel bands of 8 rows over {world} ranks + 1 gather ({'RCCL send/recv to rank 0 behind the C ABI' if not rehearsal else 'gloo REHEARSAL, ranks share GPUs'})",
                    "rays_traced": int(rays_total[0])},
     }
     info = W.device_info(gpu_index)

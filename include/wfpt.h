@@ -340,6 +340,23 @@ int wfpt_read_accumulated(wfpt_ctx *ctx, float *rgb, size_t n_floats);
 int wfpt_read_image(wfpt_ctx *ctx, float *rgb, size_t n_floats);
 /* device-to-device copy of the accumulated slab on the context's stream (for a RCCL gather) */
 int wfpt_copy_accumulated_to_device(wfpt_ctx *ctx, void *device_ptr, size_t n_bytes);
+/* ------------------------------------------------------------------ multi-GPU: RCCL gather of the band-sharded frame
+ * BUILD-SIDE ADDITION (the reference is single-GPU). One process (or thread) per GPU creates a context
+ * with tile_rank = r, tile_world = R: it renders the 8-row bands k with k % R == r, with no exchange inside the
+ * bounce loop. The only collective is this gather of the accumulated slabs to rank 0 over xGMI:
+ *   rank 0:    wfpt_comm_unique_id(id);  ... hand the 128 bytes to every rank by any means (MPI, a file, a socket) ...
+ *   all ranks: wfpt_comm_init(ctx, id, r, R);                      (collective: ncclCommInitRank on the context's device)
+ *   all ranks: wfpt_render(ctx, spp); wfpt_gather_accumulated(ctx); (asynchronous, ordered on the context's stream)
+ *   rank 0:    wfpt_read_gathered(ctx, rgb, 3 * width * height);    (blocking; the assembled frame, row-major)
+ * RCCL (librccl.so) is opened at run time; without it these calls return WFPT_ERR_UNSUPPORTED and nothing else in the
+ * library depends on it. In the pixel-keyed RNG mode the gathered frame is bit-identical to a single-GPU render. */
+#define WFPT_COMM_UNIQUE_ID_BYTES 128
+int wfpt_comm_unique_id(void *id128);
+int wfpt_comm_init(wfpt_ctx *ctx, const void *id128, int rank, int world);
+int wfpt_gather_accumulated(wfpt_ctx *ctx);
+int wfpt_read_gathered(wfpt_ctx *ctx, float *rgb, size_t n_floats);
+int wfpt_comm_destroy(wfpt_ctx *ctx); /* also done by wfpt_destroy */
+
 /* Queues in the reference's own layouts and in its (ascending-thread-index) order. */
 int wfpt_read_rays(wfpt_ctx *ctx, wfpt_ray *rays, uint32_t n);
 int wfpt_read_extension_rays(wfpt_ctx *ctx, wfpt_ray *rays, uint32_t n);

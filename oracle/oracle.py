@@ -93,6 +93,9 @@ def lib(serial=False):
     L.orc_create_mesh.restype = vp
     L.orc_create_mesh.argtypes = [C.POINTER(Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]
     L.orc_ray_steps.argtypes = [vp, u32, vp, vp]
+    L.orc_traversal_profile.argtypes = [vp, u32, vp]
+    L.orc_ray_rounds.argtypes = [vp, u32, vp, vp]
+    L.orc_sim_postpone.argtypes = [vp, u32, u32, vp]
     L.orc_write_rays.argtypes = [vp, vp, u32]
     L.orc_camera_new.argtypes = [vp, vp, C.POINTER(f32), C.POINTER(f32)]
     L.orc_view_transform.argtypes = [vp, f32, f32, vp]

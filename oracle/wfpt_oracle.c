@@ -748,7 +748,7 @@ static float hit_bvh_node(const orc_bvh_node *node, const orc_ray *ray, float ne
 typedef struct { uint64_t max_depth, nodes, tests; } trace_stat;
 
 /* ex:72-162, USE_BVH branch. The reference's stack holds 10 whole nodes with no overflow check (ex:38,
- * 135-136: undefined behaviour beyond depth 10); the oracle's stack holds 64 and aborts beyond that.
+ * 135-136: undefined behaviour beyond depth 10); the oracle's stack holds ORC_MAX_STACK (128) and aborts beyond that.
  * Storing node copies or node indices is equivalent. */
 static int trace_ray_bvh(const orc_ctx *c, const orc_ray *ray, orc_hit_payload *hit, trace_stat *st) {
     float nearest_hit = 1e30f;
@@ -816,6 +816,191 @@ int orc_trace_brute(const orc_ctx *c, const orc_ray *ray, orc_hit_payload *out) 
 int orc_trace_bvh(orc_ctx *c, const orc_ray *ray, orc_hit_payload *out) {
     trace_stat st = {0, 0, 0};
     return trace_ray_bvh(c, ray, out, &st);
+}
+
+/* Diagnostics for kernel design (not part of the chain): what the reference's traversal does on the current ray
+ * queue, summed over n rays. out[0] inner visits, [1] of them with both children entered (a push), [2] one child,
+ * [3] none (pop from an inner node), [4] leaf visits, [5] pops that found the stack empty (ray done),
+ * [6] sum over pops of the levels climbed from the current node to the popped node's parent,
+ * [8 + k] pops taken with k entries on the stack (k = 0..7, deeper ones in [15]). */
+void orc_traversal_profile(orc_ctx *c, uint32_t n, uint64_t out[16]) {
+    uint64_t acc[16] = {0};
+#pragma omp parallel
+    {
+        uint64_t loc[16] = {0};
+#pragma omp for schedule(dynamic, 1024)
+        for (int64_t idx = 0; idx < (int64_t)n; idx++) {
+            const orc_ray *ray = &c->rays[idx];
+            if (ray->pixel_idx == ORC_INACTIVE_PIXEL) continue;
+            float nearest_hit = 1e30f;
+            orc_bvh_node stack[ORC_MAX_STACK];
+            uint32_t depth_of[ORC_MAX_STACK];
+            uint32_t sp = 0, depth = 0;
+            orc_bvh_node node = c->nodes[0];
+            for (;;) {
+                int pop = 0;
+                if (node.prim_count > 0) {
+                    loc[4]++;
+                    for (uint32_t i = 0; i < node.prim_count; i++) {
+                        orc_hit_payload nh;
+                        if (hit_prim(c, ray, node.left_first + i, 0.001f, nearest_hit, &nh)) nearest_hit = nh.t;
+                    }
+                    pop = 1;
+                } else {
+                    loc[0]++;
+                    orc_bvh_node left = c->nodes[node.left_first], right = c->nodes[node.left_first + 1];
+                    float t_left = hit_bvh_node(&left, ray, nearest_hit), t_right = hit_bvh_node(&right, ray, nearest_hit);
+                    if (t_left > t_right) {
+                        float tt = t_left; t_left = t_right; t_right = tt;
+                        orc_bvh_node tn = left; left = right; right = tn;
+                    }
+                    if (t_left > nearest_hit) { loc[3]++; pop = 1; }
+                    else {
+                        node = left;
+                        depth++;
+                        if (t_right < nearest_hit) { loc[1]++; depth_of[sp] = depth; stack[sp++] = right; }
+                        else loc[2]++;
+                    }
+                }
+                if (pop) {
+                    loc[8 + (sp < 7 ? sp : 7)]++;
+                    if (sp == 0) { loc[5]++; break; }
+                    sp--;
+                    loc[6] += depth - depth_of[sp] + 1; /* levels from the current node up to the popped node's parent */
+                    node = stack[sp];
+                    depth = depth_of[sp];
+                }
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < 16; k++) acc[k] += loc[k];
+    }
+    for (int k = 0; k < 16; k++) out[k] = acc[k];
+}
+
+/* Diagnostics for kernel design: per ray, the inner visits between consecutive leaf visits ("rounds" of a
+ * while-while schedule): segs[16 * idx + k] = inner visits before the k-th leaf (k < 15; the visits after the last
+ * leaf are added to the last used slot + 1), n_leaves[idx] = leaf visits. */
+void orc_ray_rounds(orc_ctx *c, uint32_t n, uint8_t *segs, uint8_t *n_leaves) {
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t idx = 0; idx < (int64_t)n; idx++) {
+        const orc_ray *ray = &c->rays[idx];
+        uint8_t *sg = segs + 16 * idx;
+        memset(sg, 0, 16);
+        n_leaves[idx] = 0;
+        if (ray->pixel_idx == ORC_INACTIVE_PIXEL) continue;
+        float nearest_hit = 1e30f;
+        orc_bvh_node stack[ORC_MAX_STACK];
+        uint32_t sp = 0, k = 0;
+        orc_bvh_node node = c->nodes[0];
+        for (;;) {
+            int pop = 0;
+            if (node.prim_count > 0) {
+                for (uint32_t i = 0; i < node.prim_count; i++) {
+                    orc_hit_payload nh;
+                    if (hit_prim(c, ray, node.left_first + i, 0.001f, nearest_hit, &nh)) nearest_hit = nh.t;
+                }
+                if (n_leaves[idx] < 255) n_leaves[idx]++;
+                if (k < 15) k++;
+                pop = 1;
+            } else {
+                if (sg[k] < 255) sg[k]++;
+                orc_bvh_node left = c->nodes[node.left_first], right = c->nodes[node.left_first + 1];
+                float t_left = hit_bvh_node(&left, ray, nearest_hit), t_right = hit_bvh_node(&right, ray, nearest_hit);
+                if (t_left > t_right) {
+                    float tt = t_left; t_left = t_right; t_right = tt;
+                    orc_bvh_node tn = left; left = right; right = tn;
+                }
+                if (t_left > nearest_hit) pop = 1;
+                else { node = left; if (t_right < nearest_hit) stack[sp++] = right; }
+            }
+            if (pop) {
+                if (sp == 0) break;
+                node = stack[--sp];
+            }
+        }
+    }
+}
+
+/* Diagnostics for kernel design: cost model of a wave64 "while-while" schedule with up to Q postponed leaves per lane
+ * (Q = 0: a lane that reaches a leaf waits for the leaf phase, the schedule extend_kernel uses). A lane with a free
+ * slot notes the leaf, pops and keeps traversing with its `nearest` not yet updated (speculative: visits more nodes,
+ * results unchanged); the leaf phase runs when no lane can make an inner step and tests one noted leaf per lane and
+ * pass. out[0] = inner-loop iterations summed over waves, [1] = leaf passes, [2] = inner visits (lane-steps),
+ * [3] = leaf tests, [4] = waves. */
+typedef struct { orc_bvh_node node; orc_bvh_node stack[ORC_MAX_STACK]; uint32_t sp; float nearest; int done; int at_leaf;
+                 uint32_t q[8]; uint32_t nq; } sim_lane;
+static void sim_pop(sim_lane *l) { if (l->sp == 0) l->done = 1; else l->node = l->stack[--l->sp]; }
+void orc_sim_postpone(orc_ctx *c, uint32_t n, uint32_t Q, uint64_t out[8]) {
+    uint64_t iters = 0, passes = 0, visits = 0, tests = 0, waves = 0;
+    if (Q > 8) Q = 8;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : iters, passes, visits, tests, waves)
+    for (int64_t w0 = 0; w0 < (int64_t)n; w0 += 64) {
+        sim_lane *L = (sim_lane *)malloc(sizeof(sim_lane) * 64);
+        int nl = (int)((n - w0) < 64 ? (n - w0) : 64);
+        for (int i = 0; i < nl; i++) {
+            L[i].node = c->nodes[0]; L[i].sp = 0; L[i].nearest = 1e30f; L[i].nq = 0; L[i].at_leaf = 0;
+            L[i].done = c->rays[w0 + i].pixel_idx == ORC_INACTIVE_PIXEL;
+        }
+        waves++;
+        for (;;) {
+            /* inner phase */
+            for (;;) {
+                int any = 0;
+                for (int i = 0; i < nl; i++) {
+                    sim_lane *l = &L[i];
+                    if (l->done || l->at_leaf) continue;
+                    const orc_ray *ray = &c->rays[w0 + i];
+                    if (l->node.prim_count > 0) { /* arrived at a leaf by a pop */
+                        if (l->nq < Q) { l->q[l->nq++] = l->node.left_first | (l->node.prim_count << 24); sim_pop(l); if (l->done && l->nq) { l->done = 0; l->at_leaf = 2; } }
+                        else l->at_leaf = 1;
+                        continue;
+                    }
+                    any = 1;
+                    visits++;
+                    orc_bvh_node left = c->nodes[l->node.left_first], right = c->nodes[l->node.left_first + 1];
+                    float t_left = hit_bvh_node(&left, ray, l->nearest), t_right = hit_bvh_node(&right, ray, l->nearest);
+                    if (t_left > t_right) { float tt = t_left; t_left = t_right; t_right = tt; orc_bvh_node tn = left; left = right; right = tn; }
+                    if (t_left > l->nearest) { sim_pop(l); if (l->done && l->nq) { l->done = 0; l->at_leaf = 2; } }
+                    else { l->node = left; if (t_right < l->nearest) l->stack[l->sp++] = right; }
+                    /* a leaf reached by descent is handled at the top of the next iteration (costs no inner step) */
+                    if (!l->done && !l->at_leaf && l->node.prim_count > 0) {
+                        if (l->nq < Q) { l->q[l->nq++] = l->node.left_first | (l->node.prim_count << 24); sim_pop(l); if (l->done && l->nq) { l->done = 0; l->at_leaf = 2; } }
+                        else l->at_leaf = 1;
+                    }
+                }
+                if (!any) break;
+                iters++;
+            }
+            /* leaf phase: every lane tests its noted leaves (one per pass) and the leaf it waits at */
+            int alive = 0;
+            uint32_t max_pass = 0;
+            for (int i = 0; i < nl; i++) {
+                sim_lane *l = &L[i];
+                if (l->done) continue;
+                const orc_ray *ray = &c->rays[w0 + i];
+                uint32_t np = 0;
+                for (uint32_t k = 0; k < l->nq; k++) {
+                    uint32_t first = l->q[k] & 0xffffffu, cnt = l->q[k] >> 24;
+                    for (uint32_t j = 0; j < cnt; j++) { orc_hit_payload nh; tests++; if (hit_prim(c, ray, first + j, 0.001f, l->nearest, &nh)) l->nearest = nh.t; }
+                    np++;
+                }
+                l->nq = 0;
+                if (l->at_leaf == 1) {
+                    for (uint32_t j = 0; j < l->node.prim_count; j++) { orc_hit_payload nh; tests++; if (hit_prim(c, ray, l->node.left_first + j, 0.001f, l->nearest, &nh)) l->nearest = nh.t; }
+                    np++;
+                    l->at_leaf = 0;
+                    sim_pop(l);
+                } else if (l->at_leaf == 2) { l->at_leaf = 0; l->done = 1; }
+                if (np > max_pass) max_pass = np;
+                if (!l->done) alive = 1;
+            }
+            passes += max_pass;
+            if (!alive) break;
+        }
+        free(L);
+    }
+    out[0] = iters; out[1] = passes; out[2] = visits; out[3] = tests; out[4] = waves;
 }
 
 /* Diagnostics for kernel design (not part of the chain): per-ray traversal step counts of the current ray

@@ -140,6 +140,9 @@ int      orc_trace_brute(const orc_ctx *, const orc_ray *ray, orc_hit_payload *o
 int      orc_trace_bvh(orc_ctx *, const orc_ray *ray, orc_hit_payload *out);
 /* diagnostics: inner-node and leaf steps of each of the first n rays of the current ray queue */
 void     orc_ray_steps(orc_ctx *, uint32_t n, uint16_t *inner_steps, uint16_t *leaf_steps);
+void     orc_ray_rounds(orc_ctx *, uint32_t n, uint8_t *segs, uint8_t *n_leaves); /* diagnostics: inner visits per while-while round */
+void     orc_sim_postpone(orc_ctx *, uint32_t n, uint32_t Q, uint64_t out[8]); /* diagnostics: wave64 schedule model with postponed leaves */
+void     orc_traversal_profile(orc_ctx *, uint32_t n, uint64_t out[16]); /* diagnostics: push / pop / climb counts of the reference traversal */
 /* display_shader.wgsl:50-52: sqrt(acc / n) -> 8-bit RGB */
 void     orc_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb);
 int      orc_num_threads(void);

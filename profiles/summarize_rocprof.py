@@ -1,38 +1,38 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 CSV output (gpurun_out/prof_*/<host>/*_{kernel_stats,counter_collection}.csv) into the
-small summaries committed under profiles/.
+"""Condenses the rocprofv3 passes of tools/profile.sh (gpurun_out/prof_<TAG>_<pass>/...) into the small summaries
+committed under profiles/.
 
-    python profiles/summarize_rocprof.py gpurun_out r01 [n_pixels [samples per accumulate launch, comma separated]]
+    python profiles/summarize_rocprof.py gpurun_out TAG ROUND SCENE VARIANT [n_pixels]
+      e.g.   ... gpurun_out p1 r02 shirley fused
 
-Expects gpurun_out/prof_{stats,fetch,write,sq,sq2}/<host>/..., as written by
-    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py ...   (one pass per counter group)
+Writes
+  profiles/<ROUND>_kernel_stats_<SCENE>_<VARIANT>.csv   copy of rocprofv3 --kernel-trace --stats
+  profiles/<ROUND>_pmc_<SCENE>_<VARIANT>.json           per-kernel mean counter values per launch + the summary of the
+                                                         dominant kernel that bench.py reads for roofline.traffic
+  profiles/<ROUND>_bench_line_<SCENE>_<VARIANT>.json    the bench line printed by the same command (stats pass)
 
-Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc.json
-(per-kernel mean counter values per launch) and profiles/<tag>_pmc_extend.json (HBM bytes per extend launch,
-read by bench.py for roofline.traffic).
-
-FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
-(MI355X_MICROARCH.md "HBM"); other widths are uncalibrated, so the summary calibrates the read side on the
-accumulate kernel, whose byte count is known exactly (reads 2 x 12 B/pixel, writes 12 B/pixel, 16 B per lane),
-and reports both the raw and the corrected figure.
+HBM bytes: FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md "HBM"); other widths are uncalibrated, so the read side is calibrated on `accumulate_kernel`, whose
+byte count is known exactly (it reads (samples + 1) x 12 B/pixel with 16 B per lane); both raw and corrected figures are
+reported. WRITE_SIZE is exact for 16-byte-per-lane stores.
 """
 import collections
 import csv
 import glob
 import json
 import os
-import re
 import shutil
 import sys
 
-KERNELS = ["extend_kernel", "shade_kernel", "miss_kernel", "scan_kernel", "generate_rays_kernel", "accumulate_kernel"]
+NAMES = [("bounce_kernel<0", "bounce_first"), ("bounce_kernel<1", "bounce"), ("bounce_kernel<2", "bounce_last"),
+         ("extend_kernel", "extend"), ("shade_kernel", "shade"), ("miss_kernel", "miss_kernel"), ("scan_kernel", "scan"),
+         ("generate_rays_kernel", "generate_rays"), ("accumulate_kernel", "accumulate")]
 
 
 def kname(full):
-    for k in KERNELS:
-        if k in full:
-            return k
+    for needle, name in NAMES:
+        if needle in full:
+            return name
     return None
 
 
@@ -46,47 +46,65 @@ def pmc(path):
 
 
 def main():
-    src, tag = sys.argv[1], sys.argv[2]
-    n_pixels = int(sys.argv[3]) if len(sys.argv) > 3 else 1920 * 1080
-    # samples per accumulate launch, in launch order (an accumulate launch of b samples reads (b + 1) * 12 B/pixel).
-    # Default = what `bench.py --steps 64 --warmup 32` does with its 32 samples in flight: warm-up 32, prime 32,
-    # 2 x 32 timed, 2 x 32 timed again.
-    acc_batches = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [32] * 6
+    src, tag, rnd, scene, variant = sys.argv[1:6]
+    n_pixels = int(sys.argv[6]) if len(sys.argv) > 6 else 1920 * 1080
     here = os.path.dirname(os.path.abspath(__file__))
-    stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
+    base = os.path.join(src, f"prof_{tag}_")
+    stats = glob.glob(base + "stats/*/*_kernel_stats.csv")
     if stats:
-        shutil.copy(stats[0], os.path.join(here, f"{tag}_kernel_stats.csv"))
+        shutil.copy(stats[0], os.path.join(here, f"{rnd}_kernel_stats_{scene}_{variant}.csv"))
+    line = json.load(open(base + "stats.json"))
+    json.dump(line, open(os.path.join(here, f"{rnd}_bench_line_{scene}_{variant}.json"), "w"), indent=1)
     out = {}
-    for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
-        for p in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+    for d in ("fetch", "write", "sq", "sq2", "tcc"):
+        for p in glob.glob(base + d + "/*/*_counter_collection.csv"):
             for k, counters in pmc(p).items():
                 for c, v in counters.items():
                     out.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "max": max(v), "sum": sum(v)}
-    json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-    ext, acc = out.get("extend_kernel", {}), out.get("accumulate_kernel", {})
-    if "FETCH_SIZE" in ext and "WRITE_SIZE" in ext:
-        fetch_kib, write_kib = ext["FETCH_SIZE"]["mean"], ext["WRITE_SIZE"]["mean"]
+    dom = "bounce" if "bounce" in out else "extend"
+    k, acc = out.get(dom, {}), out.get("accumulate", {})
+    summary = {"kernel": dom, "bench_command": "python3 bench.py " + " ".join(sys.argv[7:]) if len(sys.argv) > 7 else None}
+    steps = line["steps"]
+    batches = line["config"]["samples_in_flight"]
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        fetch_kib, write_kib = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
         cal = None
-        if "FETCH_SIZE" in acc:
-            true_read = sum((b + 1) * 12.0 * n_pixels for b in acc_batches) / len(acc_batches)
-            cal = true_read / (acc["FETCH_SIZE"]["mean"] * 1024.0)  # true read bytes / reported
-        summary = {
-            "kernel": "extend_kernel", "launches": ext["FETCH_SIZE"]["launches"],
+        if "FETCH_SIZE" in acc and len(batches) == 1:
+            true_read = (batches[0] + 1) * 12.0 * n_pixels  # every accumulate launch of this command carries the same batch
+            cal = true_read / (acc["FETCH_SIZE"]["mean"] * 1024.0)
+        hbm = ((cal or 1.0) * fetch_kib + write_kib) * 1024.0
+        alg = line["roofline"]["algorithmic_bytes_per_launch"]
+        summary.update({
+            "launches_profiled": k["FETCH_SIZE"]["launches"],
             "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
             "fetch_calibration_on_accumulate": cal,
-            "accumulate_WRITE_SIZE_KiB_mean": acc.get("WRITE_SIZE", {}).get("mean"),
-            "note": "means over every extend launch of `python3 bench.py --steps 64 --warmup %d --no-cpu-baseline` "
-                    "(every launch carries %s samples); FETCH_SIZE x fetch_calibration (gfx950 reports half the read bytes; "
-                    % (acc_batches[0], "/".join(str(b) for b in sorted(set(acc_batches)))) +
-                    "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE is exact",
             "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024.0,
-            "hbm_bytes_per_launch": ((cal or 1.0) * fetch_kib + write_kib) * 1024.0,
-        }
-        json.dump(summary, open(os.path.join(here, f"{tag}_pmc_extend.json"), "w"), indent=1)
-        print(json.dumps(summary, indent=1))
-    for k in KERNELS:
-        if k in out:
-            print(k, {c: round(v["mean"], 1) for c, v in sorted(out[k].items())})
+            "hbm_bytes_per_launch": hbm,
+            "algorithmic_bytes_per_launch": alg,
+            "fused_design_bytes_per_launch": line["roofline"].get("fused_design_bytes_per_launch"),
+            "hbm_bytes_per_algorithmic_byte": hbm / alg,
+            "note": f"means over every launch of the dominant kernel in `bench.py --steps {steps} --warmup {line['warmup']}` "
+                    f"({batches} samples in flight); FETCH_SIZE x calibration (gfx950 reports half the bytes of wide reads; "
+                    "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE exact. bench.py scales "
+                    "hbm_bytes_per_algorithmic_byte by its own run's algorithmic bytes per launch."})
+    if "SQ_ACTIVE_INST_VALU" in k and "GRBM_GUI_ACTIVE" in k:
+        # a wave64 fp32 instruction occupies a SIMD's 32 lanes for 2 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks
+        busy = k["SQ_ACTIVE_INST_VALU"]["mean"] * 2.0 / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+        lanes = k["SQ_THREAD_CYCLES_VALU"]["mean"] / k["SQ_ACTIVE_INST_VALU"]["mean"]
+        summary["secondary"] = {"valu_busy": round(busy, 4), "lanes_per_valu_instruction": round(lanes, 2),
+                                "valu_insts_per_launch": k["SQ_INSTS_VALU"]["mean"], "salu_insts_per_launch": k["SQ_INSTS_SALU"]["mean"],
+                                "lds_insts_per_launch": k["SQ_INSTS_LDS"]["mean"]}
+        if "SQ_WAIT_ANY" in k and "SQ_WAVE_CYCLES" in k:
+            summary["secondary"]["wait_any_frac"] = round(k["SQ_WAIT_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)
+            summary["secondary"]["wait_inst_any_frac"] = round(k["SQ_WAIT_INST_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)
+    if "TCC_HIT_sum" in k:
+        summary["l2_hit_rate"] = k["TCC_HIT_sum"]["mean"] / max(k["TCC_HIT_sum"]["mean"] + k["TCC_MISS_sum"]["mean"], 1.0)
+        summary["l2_read_requests_per_launch"] = k.get("TCP_TCC_READ_REQ_sum", {}).get("mean")
+    summary["kernels"] = out
+    json.dump(summary, open(os.path.join(here, f"{rnd}_pmc_{scene}_{variant}.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({kk: vv for kk, vv in summary.items() if kk != "kernels"}, indent=1))
+    for name in sorted(out):
+        print(name, {c: round(v["mean"], 1) for c, v in sorted(out[name].items())})
 
 
 if __name__ == "__main__":

@@ -102,6 +102,26 @@ def mesh_golden():
         o.close()
 
 
+def config5_golden():
+    # (5) BASELINE config 5 at its stated size: 1 000 000-triangle soup (seed 1, 32-bin SAH), 1920x1080, 8 bounces, 1 spp,
+    # both RNG modes: per-bounce table + image hash + 16x down-sampled image (the full image would be 25 MB)
+    w, h, spp, bounces, ds, n_tri = 1920, 1080, 1, 8, 16, 1000000
+    inputs = mesh_inputs(O, w, h, n_tri)
+    for mode in (0, 1):
+        o = make_mesh_oracle(O, inputs, w, h, max_wavefronts=bounces, rng_mode=mode)
+        o.render_sample()
+        acc, table = o.accumulated(), o.bounce_table()
+        np.savez_compressed(os.path.join(HERE, f"mesh1m_1920x1080_mode{mode}.npz"), width=w, height=h, spp=spp, bounces=bounces,
+                            n_triangles=n_tri, n_bins=32, rng_mode=mode, table=table, totals=o.totals(), acc_sha256=sha(acc),
+                            acc_small=downsample(acc, w, h, ds), downsample=ds, n_nodes=len(inputs[2]))
+        print("config 5", mode, sha(acc)[:16], o.totals(), len(inputs[2]))
+        o.close()
+
+
 if __name__ == "__main__":
-    mesh_golden()
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "config5":
+        config5_golden()
+    else:
+        mesh_golden()
+        main()
+        config5_golden()

@@ -575,3 +575,74 @@ def test_large_frames(gpu, orc, w, h):
     assert np.array_equal(pt.totals(), o.totals())
     assert_bit_equal(pt.accumulated(), o.accumulated(), f"{w}x{h}")
     pt.close(); o.close()
+
+
+def test_rccl_gather_behind_the_c_abi_single_rank(gpu):
+    """wfpt_comm_unique_id / wfpt_comm_init / wfpt_gather_accumulated / wfpt_read_gathered with a one-rank communicator:
+    opens RCCL at run time, joins the communicator on the context's device and assembles the frame on the device. The
+    send / receive legs need one GPU per rank (RCCL refuses two ranks on one device), so on a one-GPU box this covers the
+    loader, ncclCommInitRank and the root's de-interleave; the band arithmetic of N > 1 is covered by tests/test_tiles_gloo.py."""
+    W = gpu
+    w, h, spp = 200, 123, 3  # 123 % 8 != 0: the last band is partial
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL)
+    uid = W.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    pt.comm_init(uid, 0, 1)
+    with pytest.raises(W.WfptError):
+        pt.comm_init(uid, 0, 1)  # already initialised
+    pt.render(spp)
+    pt.gather_accumulated()
+    assert_bit_equal(pt.gathered(), pt.accumulated(), "gathered frame of a one-rank job")
+    pt.close()
+    other = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL, tile_rank=1, tile_world=2)
+    with pytest.raises(W.WfptError):
+        other.comm_init(uid, 0, 1)  # (rank, world) must match the context's tile cut
+    with pytest.raises(W.WfptError):
+        other.gather_accumulated()  # no communicator
+    other.close()
+
+
+def test_stage_api_refuses_pixels_outside_the_image(gpu):
+    """a literal generate_rays dispatch of ceil(W/8) x ceil(H/8) tiles on a viewport that is not a multiple of 8
+    would index the image past its end in shade / miss_kernel (the reference relies on monitor-sized buffers); so would an
+    injected ray with a wild pixel_idx. Both are refused; the reference's own truncating dispatch (W/8, H/8) is accepted."""
+    W = gpu
+    w, h = 100, 100
+    pt = make_tracer(W, "shirley", w, h, batch=1)
+    pt.set_frame(W.GPUFrameBuffer.new(w, h, 1))
+    with pytest.raises(W.WfptError):
+        pt.generate_ray_kernel.run(((w + 7) // 8, (h + 7) // 8))  # 13 x 13 tiles = 10816 pixels > 10000
+    pt.generate_ray_kernel.run((w // 8, h // 8))                  # path_tracer.rs:318
+    rays = pt.rays(64).copy()
+    rays["pixel_idx"][5] = w * h  # one past the end
+    with pytest.raises(W.WfptError):
+        pt.write_rays(rays)
+    rays["pixel_idx"][5] = W.INACTIVE_PIXEL  # padding rays are fine
+    pt.write_rays(rays)
+    pt.close()
+    big = make_tracer(W, "shirley", w, h, max_window_size=13 * 13 * 64, batch=1)  # monitor-sized buffers, like the reference
+    big.set_frame(W.GPUFrameBuffer.new(w, h, 1))
+    big.generate_ray_kernel.run(((w + 7) // 8, (h + 7) // 8))
+    big.close()
+
+
+def test_wavefront_totals(gpu, orc):
+    """wfpt_read_wavefront_totals: per-wavefront (rays, hits, misses) summed over the samples of the device-resident loop
+    equal the sum of the oracle's per-sample bounce tables."""
+    W = gpu
+    w, h, spp, bounces = 160, 96, 5, 6
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+    want = np.zeros((bounces, 3), np.uint64)
+    for _ in range(spp):
+        o.render_sample()
+        t = o.bounce_table().astype(np.uint64)
+        want[:len(t), 0] += t[:, 1] + t[:, 2]
+        want[:len(t), 1] += t[:, 1]
+        want[:len(t), 2] += t[:, 2]
+    for flags in (0, W.FLAG_UNFUSED):
+        pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=4, flags=flags)
+        pt.render(spp)
+        assert np.array_equal(pt.wavefront_totals(), want), f"flags={flags}"
+        assert np.array_equal(pt.wavefront_totals().sum(axis=0), pt.totals())
+        pt.close()
+    o.close()

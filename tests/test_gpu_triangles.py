@@ -125,3 +125,40 @@ def test_obj_scene_end_to_end(gpu, orc, tmp_path):
     assert_bit_equal(pt.accumulated(), o.render(spp), "OBJ scene")
     assert pt.bounce_table()[0, 1] > w * h // 4  # the sheet fills a good part of the frame
     pt.close(); o.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config5_full_size_against_golden(gpu, mode):
+    """BASELINE config 5 at its stated size: the seeded 1 000 000-triangle soup, 1920x1080, 8 bounces, BVH built on the
+    device. One sample against the oracle's committed golden (tests/golden/mesh1m_1920x1080_mode*.npz, made by
+    tests/golden/make_golden.py config5): per-bounce (rays, hits, misses) table, totals, SHA-256 of the accumulated
+    image, its 16x down-sampled copy; then the chain's size-independent properties on further samples. Both the fused
+    bounce launches and the stage kernels one by one must give the golden image."""
+    import hashlib
+    import os
+    W = gpu
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"mesh1m_1920x1080_mode{mode}.npz"))
+    w, h, bounces, n_tri = int(g["width"]), int(g["height"]), int(g["bounces"]), int(g["n_triangles"])
+    for flags in (0, W.FLAG_UNFUSED):
+        pt = W.mesh_path_tracer(w, h, n_tri, seed=1, max_wavefronts=bounces, rng_mode=mode, device_bvh=True, batch=2, flags=flags)
+        assert len(pt.bvh_tree.nodes) == int(g["n_nodes"])
+        pt.render_sample()
+        t = pt.bounce_table().astype(np.int64)
+        assert np.array_equal(t, g["table"]), f"per-bounce table, flags={flags}"
+        acc = pt.accumulated()
+        assert np.array_equal(pt.totals(), g["totals"])
+        assert hashlib.sha256(acc.tobytes()).hexdigest() == str(g["acc_sha256"]), f"image hash, flags={flags}"
+        f = int(g["downsample"])
+        small = acc.reshape(h, w, 3)[:(h // f) * f, :(w // f) * f].reshape(h // f, f, w // f, f, 3).mean(axis=(1, 3))
+        assert np.allclose(small, g["acc_small"], rtol=1e-5, atol=1e-6)
+        # size-independent properties of the chain
+        assert t[0, 0] == w * h and (t[:, 1] + t[:, 2] == t[:, 0]).all() and (t[1:, 0] == t[:-1, 1]).all()
+        assert np.isfinite(acc).all() and acc.min() >= 0.0
+        if flags == 0:  # two more samples in one batch: accumulation is additive and frame-ordered
+            pt.render(2)
+            acc3 = pt.accumulated()
+            assert (acc3 >= acc).all() and np.isfinite(acc3).all()
+            assert int(pt.totals()[0]) > 2 * int(g["totals"][0])
+            wt = pt.wavefront_totals()
+            assert np.array_equal(wt.sum(axis=0), pt.totals()) and (wt[1:, 0] == wt[:-1, 1]).all()
+        pt.close()

@@ -157,6 +157,11 @@ def lib():
         "wfpt_read_accumulated": (i32, [vp, vp, sz]),
         "wfpt_read_image": (i32, [vp, vp, sz]),
         "wfpt_copy_accumulated_to_device": (i32, [vp, vp, sz]),
+        "wfpt_comm_unique_id": (i32, [vp]),
+        "wfpt_comm_init": (i32, [vp, vp, i32, i32]),
+        "wfpt_gather_accumulated": (i32, [vp]),
+        "wfpt_read_gathered": (i32, [vp, vp, sz]),
+        "wfpt_comm_destroy": (i32, [vp]),
         "wfpt_read_rays": (i32, [vp, vp, u32]),
         "wfpt_read_extension_rays": (i32, [vp, vp, u32]),
         "wfpt_read_hits": (i32, [vp, vp, u32]),
@@ -199,6 +204,15 @@ def _p(a):
 
 def device_count():
     return lib().wfpt_device_count()
+
+
+def comm_unique_id():
+    """Rank 0: a fresh RCCL unique id (128 bytes) to hand to every rank's PathTracer.comm_init."""
+    buf = np.zeros(128, np.uint8)
+    st = lib().wfpt_comm_unique_id(_p(buf))
+    if st != 0:
+        raise WfptError(st, lib().wfpt_last_error(None).decode())
+    return buf.tobytes()
 
 
 def device_info(device=0):
@@ -738,6 +752,22 @@ class PathTracer:
 
     def copy_accumulated_to_device(self, device_ptr, n_bytes):
         self._check(lib().wfpt_copy_accumulated_to_device(self.handle, C.c_void_p(device_ptr), n_bytes))
+
+    # ---- multi-GPU gather (RCCL behind the C ABI)
+    def comm_init(self, unique_id, rank, world):
+        """Collective over all ranks: joins the RCCL communicator named by `unique_id` (128 bytes from comm_unique_id())."""
+        buf = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        self._check(lib().wfpt_comm_init(self.handle, _p(buf), rank, world))
+
+    def gather_accumulated(self):
+        """Every rank: its slab goes to rank 0 over xGMI (asynchronous on the context's stream)."""
+        self._check(lib().wfpt_gather_accumulated(self.handle))
+
+    def gathered(self):
+        """Rank 0: the assembled (width * height, 3) accumulated frame."""
+        a = np.zeros((self.width * self.height, 3), "<f4")
+        self._check(lib().wfpt_read_gathered(self.handle, _p(a), a.size))
+        return a
 
     def rays(self, n):
         a = np.zeros(n, RAY)

@@ -5,6 +5,9 @@
 // There is no CPU fallback: without a HIP device every device entry point fails with WFPT_ERR_NO_DEVICE.
 #include "wfpt_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is opened at run time by the gather entry points
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -62,6 +65,11 @@ struct wfpt_ctx {
     uint32_t *f_miss_mem[2] = {nullptr, nullptr};
     MissQueue f_mq[2]{};
     uint32_t *f_chunk_hits[2] = {nullptr, nullptr}, *f_chunk_miss[2] = {nullptr, nullptr}, *first_seg = nullptr;
+    // multi-GPU gather of the band-sharded frame (RCCL over xGMI)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    float *gather_stage = nullptr; // root: [world - 1] slabs received from the peers
+    float *gather_frame = nullptr; // root: assembled frame, whole bands (ceil(height / 8) * 8 rows)
     uint32_t classic_batch = 1; // slices of the stage-by-stage queues: batch_max when the loop runs unfused, else 1 (stage API)
     uint32_t bounce_blocks_per_cu = 1;
     bool fused = true;
@@ -760,6 +768,7 @@ void wfpt_destroy(wfpt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)wfpt_comm_destroy(c);
     destroy_graph(c);
     for (auto &t : c->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
@@ -1133,6 +1142,156 @@ int wfpt_device_info(int device, uint32_t *compute_units, uint32_t *memory_clock
     if (memory_clock_khz) *memory_clock_khz = static_cast<uint32_t>(prop.memoryClockRate);
     if (memory_bus_width_bits) *memory_bus_width_bits = static_cast<uint32_t>(prop.memoryBusWidth);
     if (total_memory_bytes) *total_memory_bytes = static_cast<uint64_t>(prop.totalGlobalMem);
+    return WFPT_OK;
+}
+
+// ------------------------------------------------------------------ RCCL gather
+// RCCL is opened at run time, so single-GPU users of libwfpt.so carry no dependency on it and a host process that has
+// already loaded a RCCL (e.g. PyTorch's bundled copy) shares that one instead of mapping a second.
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl l;
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2 && !l.handle; ++pass) // first a copy the process already holds, then a fresh load
+            for (const char *n : names)
+                if (!l.handle) l.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if (!l.handle) { l.error = std::string("cannot open librccl.so: ") + dlerror(); return l; }
+#define WFPT_RCCL_SYM(field, sym)                                                     \
+        l.field = reinterpret_cast<decltype(l.field)>(dlsym(l.handle, #sym));          \
+        if (!l.field && l.error.empty()) l.error = "librccl.so lacks " #sym;
+        WFPT_RCCL_SYM(GetUniqueId, ncclGetUniqueId)
+        WFPT_RCCL_SYM(CommInitRank, ncclCommInitRank)
+        WFPT_RCCL_SYM(CommDestroy, ncclCommDestroy)
+        WFPT_RCCL_SYM(GroupStart, ncclGroupStart)
+        WFPT_RCCL_SYM(GroupEnd, ncclGroupEnd)
+        WFPT_RCCL_SYM(Send, ncclSend)
+        WFPT_RCCL_SYM(Recv, ncclRecv)
+        WFPT_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef WFPT_RCCL_SYM
+        return l;
+    }();
+    return r;
+}
+int rccl_fail(wfpt_ctx *c, ncclResult_t r, const char *what) {
+    return fail(c, WFPT_ERR_HIP, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error"));
+}
+#define WFPT_RCCL(c, call)                                         \
+    do {                                                           \
+        ncclResult_t r_ = (call);                                  \
+        if (r_ != ncclSuccess) return rccl_fail(c, r_, #call);     \
+    } while (0)
+
+// bands (8 pixel rows each) owned by `rank`, and the floats of its slab
+uint32_t bands_of(uint32_t height, uint32_t rank, uint32_t world) {
+    const uint32_t n_bands = (height + 7u) / 8u;
+    return n_bands > rank ? (n_bands - rank + world - 1u) / world : 0u;
+}
+} // namespace
+
+int wfpt_comm_unique_id(void *id128) {
+    if (!id128) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_comm_unique_id: null argument");
+    if (!rccl().error.empty()) return fail(nullptr, WFPT_ERR_UNSUPPORTED, rccl().error);
+    static_assert(sizeof(ncclUniqueId) == WFPT_COMM_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    WFPT_RCCL(nullptr, rccl().GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return WFPT_OK;
+}
+
+int wfpt_comm_init(wfpt_ctx *c, const void *id128, int rank, int world) {
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_comm_init: bad argument");
+    if (static_cast<uint32_t>(world) != c->tile.world || static_cast<uint32_t>(rank) != c->tile.rank)
+        return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_comm_init: (rank, world) must equal the context's (tile_rank, tile_world)");
+    if (c->comm) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_comm_init: communicator already initialised");
+    if (!rccl().error.empty()) return fail(c, WFPT_ERR_UNSUPPORTED, rccl().error);
+    WFPT_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    WFPT_RCCL(c, rccl().CommInitRank(&c->comm, world, id, rank)); // collective: every rank of the job calls it
+    c->comm_rank = rank;
+    c->comm_world = world;
+    if (rank == 0) { // the root assembles whole bands; peers' slabs land in a staging area first
+        const size_t band_floats = 8u * static_cast<size_t>(c->width) * 3u;
+        const size_t n_bands = (c->height + 7u) / 8u;
+        WFPT_HIP(c, dmalloc(&c->gather_frame, n_bands * band_floats));
+        size_t stage = 0;
+        for (int r = 1; r < world; ++r) stage += bands_of(c->height, static_cast<uint32_t>(r), static_cast<uint32_t>(world)) * band_floats;
+        WFPT_HIP(c, dmalloc(&c->gather_stage, stage));
+    }
+    return WFPT_OK;
+}
+
+int wfpt_comm_destroy(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    if (c->gather_stage) (void)hipFree(c->gather_stage);
+    if (c->gather_frame) (void)hipFree(c->gather_frame);
+    c->gather_stage = c->gather_frame = nullptr;
+    return WFPT_OK;
+}
+
+// One flat gather: every peer sends its slab of whole bands straight to the root (each peer has its own xGMI link to
+// the root, so the transfers run side by side; a ring would make the same bytes hop link after link), the root receives
+// them in one group and de-interleaves with one strided device copy per rank. Ordered after the renders on the
+// context's stream; nothing touches the host.
+int wfpt_gather_accumulated(wfpt_ctx *c) {
+    if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    if (!c->comm) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_gather_accumulated: call wfpt_comm_init first");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    const uint32_t world = static_cast<uint32_t>(c->comm_world), rank = static_cast<uint32_t>(c->comm_rank);
+    const size_t band_floats = 8u * static_cast<size_t>(c->width) * 3u;
+    if (rank != 0) {
+        const size_t count = bands_of(c->height, rank, world) * band_floats;
+        if (count) WFPT_RCCL(c, rccl().Send(c->accumulated, count, ncclFloat, 0, c->comm, c->stream));
+        return WFPT_OK;
+    }
+    if (world > 1) {
+        WFPT_RCCL(c, rccl().GroupStart());
+        size_t off = 0;
+        for (uint32_t r = 1; r < world; ++r) {
+            const size_t count = bands_of(c->height, r, world) * band_floats;
+            if (count) WFPT_RCCL(c, rccl().Recv(c->gather_stage + off, count, ncclFloat, static_cast<int>(r), c->comm, c->stream));
+            off += count;
+        }
+        WFPT_RCCL(c, rccl().GroupEnd());
+    }
+    // band k of the frame is band k / world of rank k % world's slab: one strided device copy per rank
+    size_t off = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        const uint32_t nb = bands_of(c->height, r, world);
+        const float *src = r == 0 ? c->accumulated : c->gather_stage + off;
+        if (r != 0) off += nb * band_floats;
+        const size_t n_valid = r == 0 ? 3u * static_cast<size_t>(c->n_pixels) : nb * band_floats;
+        WFPT_HIP(c, launch_band_scatter(c->gather_frame, src, n_valid, band_floats, world, r, c->stream));
+    }
+    return WFPT_OK;
+}
+
+int wfpt_read_gathered(wfpt_ctx *c, float *rgb, size_t n_floats) {
+    if (!c || !rgb) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_gathered: null argument");
+    if (!c->gather_frame) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_read_gathered: only the root rank of an initialised communicator holds the frame");
+    if (n_floats > 3u * static_cast<size_t>(c->width) * c->height) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "n_floats exceeds the frame");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, hipMemcpy(rgb, c->gather_frame, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
     return WFPT_OK;
 }
 

@@ -259,6 +259,8 @@ hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s);
+// frame band (j * world + rank) <- slab band j for the first n_valid floats of a slab: the root of the multi-GPU gather
+hipError_t launch_band_scatter(float *frame, const float *slab, size_t n_valid, size_t band_floats, uint32_t world, uint32_t rank, hipStream_t s);
 // AoS <-> SoA converters for the read-back / injection paths
 hipError_t launch_rays_to_aos(const RayQueue &q, wfpt_ray *out, uint32_t n, hipStream_t s);
 hipError_t launch_rays_from_aos(const RayQueue &q, const wfpt_ray *in, uint32_t n, hipStream_t s);

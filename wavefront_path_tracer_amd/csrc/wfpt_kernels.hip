@@ -164,6 +164,39 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
     return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
 }
 
+// The same test with each plane distance as ONE fused multiply-add, b * inv + (-(o * inv)): half the arithmetic of
+// (b - o) * inv. It is NOT the reference's rounding, so it is used only where a box test cannot change the result:
+// for spheres. The closest hit is the minimum over the spheres whose exact test (hit_prim) accepts, whatever boxes are
+// visited on the way; a box test only has to be conservative for the sphere it bounds. Both forms are within an ulp or
+// two of the true plane distances and can disagree only for rays that graze a box edge or corner within that error,
+// and a sphere touches its (and every enclosing) box at face centres only, a distance (sqrt(2) - 1) r away from the
+// nearest edge. Infinite inverses (axis-parallel rays) are clamped first, see trace_ray. Triangles reach the corners
+// of their boxes, so they keep the exact form.
+// Gate: every bit-exact test, and bench.py's comparison of the whole 64-spp full-HD frame with the oracle.
+__device__ __forceinline__ float hit_bvh_node_fma(float4 bmin, float4 bmax, float nox, float noy, float noz, float ix,
+                                                  float iy, float iz, float nearest) {
+    const float t_x_min = fma_(bmin.x, ix, nox);
+    const float t_x_max = fma_(bmax.x, ix, nox);
+    float tmin = min_(t_x_min, t_x_max);
+    float tmax = max_(t_x_min, t_x_max);
+    const float t_y_min = fma_(bmin.y, iy, noy);
+    const float t_y_max = fma_(bmax.y, iy, noy);
+    tmin = max_(min_(t_y_min, t_y_max), tmin);
+    tmax = min_(max_(t_y_min, t_y_max), tmax);
+    const float t_z_min = fma_(bmin.z, iz, noz);
+    const float t_z_max = fma_(bmax.z, iz, noz);
+    tmin = max_(min_(t_z_min, t_z_max), tmin);
+    tmax = min_(max_(t_z_min, t_z_max), tmax);
+    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
+}
+
+#ifndef WFPT_SLAB_FMA
+#define WFPT_SLAB_FMA 1 // spheres: one fma per box plane (see hit_bvh_node_fma)
+#endif
+#ifndef WFPT_BUDGET_INNER
+#define WFPT_BUDGET_INNER 0 // 1: count the step budget down on every inner visit as well (costs 3 instructions per visit)
+#endif
+
 // Marks all four components of loaded float4s as used, so each load stays one ds_read_b128 (hipcc otherwise
 // narrows a load whose .w is consumed elsewhere to ds_read_b96 + ds_read_b32: 2.5x the LDS cycles). Input-only
 // and placed after ALL loads of a step, so the loads issue back to back and are waited for once.
@@ -219,6 +252,7 @@ struct Traversal {
         // levels to climb to the deepest pending sibling = trailing zeros
         const uint32_t up = (sizeof(Trail) == 8) ? static_cast<uint32_t>(__ffsll(static_cast<long long>(trail)) - 1)
                                                  : static_cast<uint32_t>(__ffs(static_cast<int>(trail)) - 1);
+        trail = (trail >> up) & ~static_cast<Trail>(1); // now at that level, its pending flag consumed
         uint32_t fields = 0xffffffffu;
         if (STACK_DEPTH > 0 && lost == 0) {
             sp -= 1;
@@ -229,7 +263,6 @@ struct Traversal {
             node ^= 1u;
             if (STACK_DEPTH > 0) lost -= 1;
         }
-        trail = (trail >> up) & ~static_cast<Trail>(1); // now at that level, its pending flag consumed
         if (STACK_DEPTH > 0 && fields != 0xffffffffu) {
             left_first = fields >> kMetaCountBits;
             prim_count = fields & ((1u << kMetaCountBits) - 1u);
@@ -303,18 +336,30 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     tr.prim_count = __float_as_uint(nodes[1].w);
     tr.trail = 0;
     bool alive = true;
-    // A traversal visits every node at most once, so `max_steps` (= node count) is never reached on a valid
-    // tree; it only guarantees that every wave terminates if the node data is corrupt.
+    constexpr bool kFmaSlab = WFPT_SLAB_FMA != 0 && PRIM == 0;
+    // fused form: an infinite inverse (a direction component that is exactly zero, or denormal) would turn b * inv - o * inv
+    // into inf - inf for one plane of a slab and cull boxes the ray is inside of. Clamped to +-1e30 the two planes of an
+    // axis-parallel ray keep their signs (|b - o| * 1e30 stays finite for any sane scene) and the slab reads "always" or
+    // "never" exactly like the reference's +-inf. (A NaN inverse means a NaN direction: no sphere test can pass anyway.)
+    const float bx = kFmaSlab ? min_(max_(ix, -1e30f), 1e30f) : ix, by = kFmaSlab ? min_(max_(iy, -1e30f), 1e30f) : iy,
+                bz = kFmaSlab ? min_(max_(iz, -1e30f), 1e30f) : iz;
+    const float nox = kFmaSlab ? -(ox * bx) : ox, noy = kFmaSlab ? -(oy * by) : oy, noz = kFmaSlab ? -(oz * bz) : oz;
+    // A traversal visits every node at most once, so `max_steps` (= node count) is never reached on a valid tree (the
+    // tree is validated at wfpt_create: sibling layout, ranges, no cycles); the budget only guarantees that every wave
+    // terminates if the node data were corrupt. It is counted per leaf / pop round; a descent between two leaves is at
+    // most `depth` inner visits long on a validated tree.
     uint32_t budget = max_steps;
     while (alive) {
         // ---- inner nodes (ex:105-138)
         while (alive && tr.prim_count == 0) {
-            if (budget-- == 0) { alive = false; break; }
+            if (WFPT_BUDGET_INNER && budget-- == 0) { alive = false; break; }
             const float4 *pair = nodes + 2u * tr.left_first;
             const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
             keep4(lmin, lmax, rmin, rmax);
-            const float t_left = hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
-            const float t_right = hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_left = kFmaSlab ? hit_bvh_node_fma(lmin, lmax, nox, noy, noz, bx, by, bz, nearest)
+                                          : hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_right = kFmaSlab ? hit_bvh_node_fma(rmin, rmax, nox, noy, noz, bx, by, bz, nearest)
+                                           : hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
             const bool swap = t_left > t_right; // strict: ties keep the left child first
             const float t_near = swap ? t_right : t_left;
             const float t_far = swap ? t_left : t_right;
@@ -1100,6 +1145,15 @@ __global__ void fill_kernel(float *p, float v, size_t n) {
         p[i] = v;
 }
 
+// Multi-GPU gather, root side: band j of rank `rank`'s slab is band j * world + rank of the frame. `n_valid` floats of
+// the slab exist (an unsharded context holds width * height pixels, not whole bands).
+__global__ void band_scatter_kernel(float *frame, const float *slab, size_t n_valid, uint32_t band_floats, uint32_t world, uint32_t rank) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n_valid; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t band = i / band_floats, k = i - band * band_floats;
+        frame[(band * world + rank) * band_floats + k] = slab[i];
+    }
+}
+
 __global__ void rays_to_aos_kernel(RayQueue q, wfpt_ray *out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1269,6 +1323,14 @@ hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(fill_kernel, dim3(static_cast<uint32_t>(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_band_scatter(float *frame, const float *slab, size_t n_valid, size_t band_floats, uint32_t world, uint32_t rank, hipStream_t s) {
+    if (n_valid == 0) return hipSuccess;
+    const size_t blocks = (n_valid + 255) / 256;
+    hipLaunchKernelGGL(band_scatter_kernel, dim3(static_cast<uint32_t>(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, frame, slab, n_valid,
+                       static_cast<uint32_t>(band_floats), world, rank);
     return hipGetLastError();
 }
 
