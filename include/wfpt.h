@@ -277,6 +277,26 @@ wfpt_ctx *wfpt_create_mesh(const wfpt_params *params,
 void wfpt_destroy(wfpt_ctx *ctx);
 const char *wfpt_last_error(const wfpt_ctx *ctx);
 
+/* Image chunking on one GPU (the reference's to-do "split rendering of image into chunks so that the buffers aren't so
+ * big", README.md:20): renders n_samples of the whole frame as `chunks` band-interleaved slabs, one context after the
+ * other (chunk k holds the 8-row bands j with j % chunks == k, so every device buffer is sized for 1/chunks of the
+ * frame), and writes the accumulated frame (3 floats per pixel, row-major, width * height pixels) to host memory at
+ * `rgb`. params->tile_rank / tile_world / max_pixels are ignored. With chunks > 1 params->rng_mode must be
+ * WFPT_RNG_PIXEL (the dispatch-keyed RNG of shade.wgsl:72 depends on a ray's queue position, hence on the cut); the
+ * frame is then bit-identical to the unchunked WFPT_RNG_PIXEL render. Blocking. */
+int wfpt_render_chunked(const wfpt_params *params,
+                        const wfpt_sphere *spheres, uint32_t n_spheres,
+                        const wfpt_material *materials, uint32_t n_materials,
+                        const wfpt_bvh_node *nodes, uint32_t n_nodes,
+                        const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16],
+                        uint32_t n_samples, uint32_t chunks, float *rgb);
+int wfpt_render_chunked_mesh(const wfpt_params *params,
+                             const wfpt_triangle *triangles, uint32_t n_triangles,
+                             const wfpt_material *materials, uint32_t n_materials,
+                             const wfpt_bvh_node *nodes, uint32_t n_nodes,
+                             const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16],
+                             uint32_t n_samples, uint32_t chunks, float *rgb);
+
 /* frame_buffer.queue_for_gpu (path_tracer.rs:296-297, 366-367). The uniform set here is what the STAGE API
  * (wfpt_kernel_run) reads. The device-resident loop (wfpt_render_sample / wfpt_render) owns the frame uniform like
  * PathTracer::run does (path_tracer.rs:293-297): its next call overwrites it with {width, height,

@@ -94,3 +94,34 @@ def test_product_never_touches_the_oracle():
                     text = open(os.path.join(dirpath, f)).read()
                     assert "orc_" not in text and "wfpt_oracle" not in text and "from oracle" not in text \
                         and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_wfpt_sys_crate_matches_the_header(wf):
+    """wfpt-sys/ (the Rust -sys crate a maintainer of the reference would depend on; uncompiled here, the image has no Rust):
+    src/lib.rs is what tools/gen_wfpt_sys.py generates from include/wfpt.h today, its extern "C" list is exactly the
+    header's function list, and every name is exported by the built library."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    committed = open(os.path.join(root, "wfpt-sys", "src", "lib.rs")).read()
+    fresh = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wfpt_sys.py"), "--stdout"], check=True,
+                           stdout=subprocess.PIPE, text=True).stdout
+    assert committed == fresh, "wfpt-sys/src/lib.rs is stale: run python tools/gen_wfpt_sys.py"
+    rust_fns = re.findall(r"pub fn (wfpt_[a-z0-9_]+)\(", committed)
+    assert sorted(rust_fns) == wf.abi_symbols() and len(set(rust_fns)) == len(rust_fns)
+    L = wf.lib()
+    for name in rust_fns:
+        assert hasattr(L, name), f"libwfpt.so does not export {name}"
+    # struct sizes as Rust would lay them out (#[repr(C)], 4-byte scalars only) against the header's static asserts
+    sizes = {}
+    for name, body in re.findall(r"pub struct (wfpt_\w+) \{(.*?)\n\}", committed, flags=re.S):
+        n = 0
+        for m in re.finditer(r"pub \w+: (?:\[(?:f32|u32|i32); (\d+)\]|(f32|u32|i32)),", body):
+            n += 4 * int(m.group(1)) if m.group(1) else 4
+        sizes[name] = n
+    assert sizes["wfpt_sphere"] == 32 and sizes["wfpt_material"] == 32 and sizes["wfpt_bvh_node"] == 32
+    assert sizes["wfpt_gpu_camera"] == 32 and sizes["wfpt_frame_buffer"] == 16 and sizes["wfpt_ray"] == 48
+    assert sizes["wfpt_hit_payload"] == 16 and sizes["wfpt_triangle"] == 48 and sizes["wfpt_params"] == 44
+    cargo = open(os.path.join(root, "wfpt-sys", "Cargo.toml")).read()
+    assert 'links = "wfpt"' in cargo and os.path.exists(os.path.join(root, "wfpt-sys", "build.rs"))

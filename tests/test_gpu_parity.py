@@ -217,6 +217,14 @@ def test_tile_sharding_pixel_mode(gpu, orc):
     assert probe.ray_capacity < full.ray_capacity / 4
     probe.close()
     assert_bit_equal(tiles.render_in_chunks(chunk, w, h, spp, 5), ref, "rendered in 5 chunks")
+    # the same behind the C ABI (wfpt_render_chunked): one call, frame assembled into the caller's buffer; 225 % 8 != 0
+    cc = W.CameraController(W.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
+    rp = W.RenderParameters(cc, (w, h))
+    for chunks in (1, 5, 29):  # 29 bands: one band per chunk
+        scene = W.Scene.book_one_final(1)  # fresh: building the BVH reorders the spheres in place
+        assert_bit_equal(W.render_chunked(scene, rp, spp, chunks, max_wavefronts=4), ref, f"wfpt_render_chunked, {chunks} chunks")
+    with pytest.raises(W.WfptError):
+        W.render_chunked(W.Scene.book_one_final(1), rp, spp, 3, max_wavefronts=4, rng_mode=W.RNG_DISPATCH)  # the dispatch-keyed RNG depends on the cut
     full.close()
 
 

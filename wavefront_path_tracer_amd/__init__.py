@@ -120,6 +120,8 @@ def lib():
         "wfpt_load_obj": (i32, [C.c_char_p, vp, u32, C.POINTER(u32), u32, u32]),
         "wfpt_scene_random_mesh": (u32, [C.c_uint64, u32, vp, vp]),
         "wfpt_create_mesh": (vp, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]),
+        "wfpt_render_chunked": (i32, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp, u32, u32, vp]),
+        "wfpt_render_chunked_mesh": (i32, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp, u32, u32, vp]),
         "wfpt_camera_new": (None, [vp, vp, C.POINTER(f32), C.POINTER(f32)]),
         "wfpt_view_transform": (None, [vp, f32, f32, vp]),
         "wfpt_p_inv": (None, [f32, f32, f32, f32, vp]),
@@ -818,6 +820,33 @@ class PathTracer:
         n = C.c_uint32()
         self._check(lib().wfpt_read_wavefront_totals(self.handle, _p(t), 64, C.byref(n)))
         return t[:n.value].copy()
+
+
+def render_chunked(scene, rp, spp, chunks, max_wavefronts=50, miss_floor=128, rng_mode=RNG_PIXEL, flags=0, device=0, batch=0,
+                   mesh_bins=32):
+    """wfpt_render_chunked: the frame as `chunks` band-interleaved slabs rendered one after the other on one GPU (README.md:20),
+    assembled on the host; returns the accumulated (width * height, 3) image. Builds the BVH like PathTracer does."""
+    L = lib()
+    cc = rp.camera_controller()
+    w, h = rp.viewport_size()
+    z_near, z_far = cc.get_clip_planes()
+    proj = ProjectionMatrix(cc.vfov_rad(), np.float32(w) / np.float32(h), z_near, z_far).p_inv()
+    view, cam = cc.get_view_matrix(), cc.get_GPU_camera()
+    params = _Params(w, h, 0, max_wavefronts, miss_floor, rng_mode, flags, 0, 1, device, batch)
+    out = np.zeros((w * h, 3), "<f4")
+    if scene.triangles is not None:
+        bvh = BVHTree(len(scene.triangles))
+        bvh.build_bvh_tree_triangles(scene.triangles, mesh_bins)
+        st = L.wfpt_render_chunked_mesh(C.byref(params), _p(scene.triangles), len(scene.triangles), _p(scene.materials), len(scene.materials),
+                                        _p(bvh.nodes), len(bvh.nodes), _p(cam), _p(proj), _p(view), spp, chunks, _p(out))
+    else:
+        bvh = BVHTree(len(scene.spheres))
+        bvh.build_bvh_tree(scene.spheres)
+        st = L.wfpt_render_chunked(C.byref(params), _p(scene.spheres), len(scene.spheres), _p(scene.materials), len(scene.materials),
+                                   _p(bvh.nodes), len(bvh.nodes), _p(cam), _p(proj), _p(view), spp, chunks, _p(out))
+    if st != 0:
+        raise WfptError(st, L.wfpt_last_error(None).decode())
+    return out
 
 
 def shirley_path_tracer(width, height, seed=1, **kw):

@@ -33,6 +33,12 @@ namespace wfpt {
 void set_last_error(const std::string &msg) { g_last_error = msg; } // for entry points without a context (wfpt_bvh_build.hip)
 } // namespace wfpt
 
+// 8-row bands of an image of `height` rows owned by rank `rank` of `world` (band k belongs to rank k % world)
+static uint32_t bands_of(uint32_t height, uint32_t rank, uint32_t world) {
+    const uint32_t n_bands = (height + 7u) / 8u;
+    return n_bands > rank ? (n_bands - rank + world - 1u) / world : 0u;
+}
+
 struct wfpt_ctx {
     wfpt_params p{};
     int device = 0;
@@ -764,6 +770,63 @@ wfpt_ctx *wfpt_create_mesh(const wfpt_params *params, const wfpt_triangle *trian
     return create_impl(params, nullptr, triangles, n_triangles, materials, n_materials, nodes, n_nodes, camera, inv_proj, view);
 }
 
+// Image chunking (README.md:20 "split rendering of image into chunks so that the buffers aren't so big"): the band cut of
+// the multi-GPU path on ONE device. Chunk k of `chunks` is a context with tile_rank = k, tile_world = chunks, so every
+// queue and image buffer is sized for 1/chunks of the frame; the chunks render one after the other and their slabs are
+// interleaved into the caller's frame.
+static int render_chunked_impl(const wfpt_params *params, const wfpt_sphere *spheres, const wfpt_triangle *triangles, uint32_t n_prims,
+                               const wfpt_material *materials, uint32_t n_materials, const wfpt_bvh_node *nodes, uint32_t n_nodes,
+                               const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16], uint32_t n_samples,
+                               uint32_t chunks, float *rgb) {
+    if (!params || !rgb || chunks == 0) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_chunked: null or empty argument");
+    if (chunks > 1 && params->rng_mode != WFPT_RNG_PIXEL)
+        return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT,
+                    "wfpt_render_chunked: WFPT_RNG_DISPATCH keys shade's RNG on a ray's queue position, which depends on the cut; "
+                    "use WFPT_RNG_PIXEL to get the unchunked image");
+    const uint32_t w = params->width, h = params->height;
+    const size_t band_floats = 8u * static_cast<size_t>(w) * 3u;
+    std::vector<float> slab;
+    for (uint32_t k = 0; k < chunks; ++k) {
+        wfpt_params p = *params;
+        p.tile_rank = k;
+        p.tile_world = chunks;
+        p.max_pixels = 0;
+        wfpt_ctx *c = create_impl(&p, spheres, triangles, n_prims, materials, n_materials, nodes, n_nodes, camera, inv_proj, view);
+        if (!c) return WFPT_ERR_HIP; // wfpt_last_error(NULL) holds the reason
+        int r = wfpt_render(c, n_samples);
+        if (r == WFPT_OK) {
+            slab.resize(3 * static_cast<size_t>(c->n_pixels));
+            r = wfpt_read_accumulated(c, slab.data(), slab.size());
+        }
+        if (r != WFPT_OK) {
+            g_last_error = c->err;
+            wfpt_destroy(c);
+            return r;
+        }
+        const uint32_t nb = bands_of(h, k, chunks);
+        for (uint32_t j = 0; j < nb; ++j) { // band j of this chunk is band j * chunks + k of the frame (the last one may be partial)
+            const uint32_t y0 = (j * chunks + k) * 8u, rows = std::min(8u, h - y0);
+            std::memcpy(rgb + static_cast<size_t>(y0) * w * 3u, slab.data() + j * band_floats, sizeof(float) * rows * w * 3u);
+        }
+        wfpt_destroy(c);
+    }
+    return WFPT_OK;
+}
+
+int wfpt_render_chunked(const wfpt_params *params, const wfpt_sphere *spheres, uint32_t n_spheres, const wfpt_material *materials,
+                        uint32_t n_materials, const wfpt_bvh_node *nodes, uint32_t n_nodes, const wfpt_gpu_camera *camera,
+                        const float inv_proj[16], const float view[16], uint32_t n_samples, uint32_t chunks, float *rgb) {
+    if (!spheres) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_chunked: null argument");
+    return render_chunked_impl(params, spheres, nullptr, n_spheres, materials, n_materials, nodes, n_nodes, camera, inv_proj, view, n_samples, chunks, rgb);
+}
+
+int wfpt_render_chunked_mesh(const wfpt_params *params, const wfpt_triangle *triangles, uint32_t n_triangles, const wfpt_material *materials,
+                             uint32_t n_materials, const wfpt_bvh_node *nodes, uint32_t n_nodes, const wfpt_gpu_camera *camera,
+                             const float inv_proj[16], const float view[16], uint32_t n_samples, uint32_t chunks, float *rgb) {
+    if (!triangles) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_render_chunked_mesh: null argument");
+    return render_chunked_impl(params, nullptr, triangles, n_triangles, materials, n_materials, nodes, n_nodes, camera, inv_proj, view, n_samples, chunks, rgb);
+}
+
 void wfpt_destroy(wfpt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -1194,11 +1257,6 @@ int rccl_fail(wfpt_ctx *c, ncclResult_t r, const char *what) {
         if (r_ != ncclSuccess) return rccl_fail(c, r_, #call);     \
     } while (0)
 
-// bands (8 pixel rows each) owned by `rank`, and the floats of its slab
-uint32_t bands_of(uint32_t height, uint32_t rank, uint32_t world) {
-    const uint32_t n_bands = (height + 7u) / 8u;
-    return n_bands > rank ? (n_bands - rank + world - 1u) / world : 0u;
-}
 } // namespace
 
 int wfpt_comm_unique_id(void *id128) {
