@@ -54,6 +54,7 @@ def parse():
                     help="auto: dispatch (reference-faithful) on 1 GPU, pixel (shard-invariant) on N > 1")
     ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--binary-bvh", action="store_true", help="mesh scene: walk the binary tree instead of the four-wide collapse")
     ap.add_argument("--unfused", action="store_true", help="run the stage kernels one by one (extend, scan, shade, miss_kernel per wavefront)")
     ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,7 +157,7 @@ def main():
     mode_name = args.rng_mode if args.rng_mode != "auto" else ("dispatch" if world == 1 else "pixel")
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
-             (W.FLAG_UNFUSED if args.unfused else 0))
+             (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0))
     # samples in flight per launch: 32 at N=1 (16 -> 32 -> 64: 13.5 -> 14.0 -> 14.1 Grays/s, mostly fewer scan launches);
     # each rank of N holds 1/N of the pixels, so scale it to keep launches as large
     batch = args.batch or min(64, 32 * world)
@@ -277,6 +278,8 @@ def main():
                    "step": "one sample per pixel: generate_rays -> bounces x (extend, scan, shade, miss_kernel) -> accumulate",
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
                    "loop": "fused bounce launches" if fused else "stage kernels one by one",
+                   "traversal": ("LDS-resident binary BVH" if args.scene == "shirley" else
+                                 ("binary BVH from HBM" if args.binary_bvh else "four-wide collapsed BVH (128-byte nodes) from HBM")),
                    "launch": "direct" if args.no_graph else "hipGraph",
                    "samples_in_flight": sorted({min(batch, args.steps), args.steps % batch} - {0}, reverse=True),
                    "parallelism": "single GPU" if world == 1 else
@@ -291,6 +294,8 @@ def main():
         avg_s = stage["k_ms"] * 1e-3 / max(stage["k_n"], 1)
         achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         variant = "split" if args.split_shade else ("unfused" if args.unfused else "fused")
+        if args.binary_bvh:
+            variant += "_binary"
         pmc = load_pmc(args.scene, variant)
         # PMC traffic is a property of (scene, loop variant): the profile stores HBM bytes per algorithmic byte of the
         # same kernel on the same workload, scaled here by this run's algorithmic bytes per launch; null without a profile

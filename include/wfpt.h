@@ -176,9 +176,11 @@ typedef enum wfpt_rng_mode { WFPT_RNG_DISPATCH = 0, WFPT_RNG_PIXEL = 1 } wfpt_rn
 enum {
     WFPT_FLAG_SPLIT_SHADE = 1u << 0, /* fused loop runs the three per-material shade stages */
     WFPT_FLAG_NO_GRAPH = 1u << 1,    /* fused loop launches kernels directly instead of replaying a hipGraph */
-    WFPT_FLAG_UNFUSED = 1u << 2      /* device-resident loop runs the stage kernels one by one (extend, scan, shade,
+    WFPT_FLAG_UNFUSED = 1u << 2,     /* device-resident loop runs the stage kernels one by one (extend, scan, shade,
                                         miss_kernel per wavefront) instead of one fused bounce launch per wavefront.
                                         Same images bit for bit; WFPT_FLAG_SPLIT_SHADE implies it. */
+    WFPT_FLAG_BINARY_BVH = 1u << 3   /* scenes too large for LDS: walk the caller's binary tree as it is instead of the
+                                        four-wide collapse built at wfpt_create (same hits; for comparisons) */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu

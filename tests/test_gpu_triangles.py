@@ -57,10 +57,12 @@ def test_mesh_device_loop(gpu, orc, n_tris, scale, w, h):
     spp, bounces = 5, 6
     o = make_mesh_oracle(orc, mesh_inputs(orc, w, h, n_tris, scale), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    for batch in (1, 4):
-        pt = make_mesh_tracer(W, w, h, n_tris, scale, max_wavefronts=bounces, batch=batch)
+    # fused bounce launches / stage kernels one by one; four-wide collapsed tree (default for scenes beyond LDS) / the caller's
+    # binary tree as it is: all four must give the oracle's image
+    for batch, flags in ((1, 0), (4, 0), (4, W.FLAG_BINARY_BVH), (4, W.FLAG_UNFUSED), (2, W.FLAG_UNFUSED | W.FLAG_BINARY_BVH)):
+        pt = make_mesh_tracer(W, w, h, n_tris, scale, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
-        assert_bit_equal(pt.accumulated(), want, f"mesh image, batch {batch}")
+        assert_bit_equal(pt.accumulated(), want, f"mesh image, batch {batch}, flags {flags}")
         assert np.array_equal(pt.totals(), o.totals())
         assert np.array_equal(pt.bounce_table(), o.bounce_table())
         pt.close()

@@ -86,6 +86,9 @@ struct wfpt_ctx {
     float4 *d_sphere_geom = nullptr;
     uint16_t *d_pair_parent = nullptr;
     uint32_t *d_pair_parent32 = nullptr;
+    float4 *d_nodes4 = nullptr;      // HBM-resident scenes: the tree collapsed into four-wide nodes
+    uint32_t *d_stack_spill = nullptr;
+    uint32_t depth4 = 0;
     wfpt_sphere *d_spheres = nullptr;
     wfpt_triangle *d_triangles = nullptr;
     wfpt_material *d_materials = nullptr;
@@ -170,6 +173,66 @@ int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint
     if (max_depth > static_cast<uint32_t>(kMaxTrailDepth))
         return fail(c, WFPT_ERR_UNSUPPORTED, "BVH deeper than 63 levels");
     return static_cast<int>(max_depth);
+}
+
+// Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into four-wide nodes: the children of node N are
+// its grandchildren where a child is an inner node, and the child itself where it is a leaf. Returns false when a leaf
+// cannot be written as a child word (more than kLeafMaxCount primitives or an index beyond 28 bits): the caller then keeps
+// the binary traversal. `depth4` = levels of four-wide nodes below the root node.
+bool collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vector<Node4> &out, uint32_t &depth4) {
+    out.clear();
+    depth4 = 0;
+    auto leaf_word = [&](const wfpt_bvh_node &nd, uint32_t &w) {
+        if (nd.prim_count > kLeafMaxCount || nd.left_first > kLeafFirstMask) return false;
+        w = kLeafFlag | (nd.prim_count << kLeafCountShift) | nd.left_first;
+        return true;
+    };
+    struct Item { uint32_t bin, slot, depth; }; // binary inner node -> its four-wide node `slot`
+    std::vector<Item> todo;
+    out.emplace_back();
+    if (nodes[0].prim_count > 0) { // a single leaf: a root node with one leaf child (its box is never tested by the reference either)
+        Node4 &r = out[0];
+        for (int k = 0; k < 4; ++k) r.child[k] = kEmptyChild, r.pad[k] = 0;
+        for (int k = 0; k < 4; ++k) r.min_x[k] = r.min_y[k] = r.min_z[k] = r.max_x[k] = r.max_y[k] = r.max_z[k] = 0.0f;
+        r.min_x[0] = nodes[0].aabb_min[0]; r.min_y[0] = nodes[0].aabb_min[1]; r.min_z[0] = nodes[0].aabb_min[2];
+        r.max_x[0] = nodes[0].aabb_max[0]; r.max_y[0] = nodes[0].aabb_max[1]; r.max_z[0] = nodes[0].aabb_max[2];
+        return leaf_word(nodes[0], r.child[0]);
+    }
+    todo.push_back({0u, 0u, 0u});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        depth4 = std::max(depth4, it.depth);
+        uint32_t kids[4], n_kids = 0;
+        const uint32_t l = nodes[it.bin].left_first;
+        for (uint32_t c = l; c <= l + 1u; ++c) {
+            if (nodes[c].prim_count > 0) kids[n_kids++] = c;
+            else { kids[n_kids++] = nodes[c].left_first; kids[n_kids++] = nodes[c].left_first + 1u; }
+        }
+        Node4 nd4{};
+        for (uint32_t k = 0; k < 4; ++k) {
+            nd4.pad[k] = 0;
+            if (k >= n_kids) {
+                nd4.child[k] = kEmptyChild;
+                nd4.min_x[k] = nd4.min_y[k] = nd4.min_z[k] = nd4.max_x[k] = nd4.max_y[k] = nd4.max_z[k] = 0.0f;
+                continue;
+            }
+            const wfpt_bvh_node &ch = nodes[kids[k]];
+            nd4.min_x[k] = ch.aabb_min[0]; nd4.min_y[k] = ch.aabb_min[1]; nd4.min_z[k] = ch.aabb_min[2];
+            nd4.max_x[k] = ch.aabb_max[0]; nd4.max_y[k] = ch.aabb_max[1]; nd4.max_z[k] = ch.aabb_max[2];
+            if (ch.prim_count > 0) {
+                if (!leaf_word(ch, nd4.child[k])) return false;
+            } else {
+                if (out.size() >= kLeafFlag) return false;
+                nd4.child[k] = static_cast<uint32_t>(out.size());
+                todo.push_back({kids[k], static_cast<uint32_t>(out.size()), it.depth + 1u});
+                out.emplace_back();
+            }
+        }
+        out[it.slot] = nd4;
+    }
+    (void)n_nodes;
+    return true;
 }
 
 void destroy_graph(wfpt_ctx *c) {
@@ -710,6 +773,14 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         CREATE_HIP(dmalloc(&c->d_pair_parent32, pair_parent.size()));
         CREATE_HIP(hipMemcpy(c->d_pair_parent32, pair_parent.data(), sizeof(uint32_t) * pair_parent.size(), hipMemcpyHostToDevice));
     }
+    if (!lds_scene && !(params->flags & WFPT_FLAG_BINARY_BVH)) { // four-wide nodes for the HBM-resident traversal
+        std::vector<Node4> n4;
+        if (collapse_bvh4(nodes, n_nodes, n4, c->depth4)) {
+            CREATE_HIP(dmalloc(&c->d_nodes4, 8 * n4.size()));
+            CREATE_HIP(hipMemcpy(c->d_nodes4, n4.data(), sizeof(Node4) * n4.size(), hipMemcpyHostToDevice));
+            c->scene.nodes4 = c->d_nodes4;
+        }
+    }
     c->scene.nodes = c->d_nodes;
     c->scene.pair_parent = c->d_pair_parent;
     c->scene.pair_parent32 = c->d_pair_parent32;
@@ -743,6 +814,13 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     int bounce_blocks = 1;
     CREATE_HIP(bounce_blocks_per_cu(c->scene, &bounce_blocks));
     c->bounce_blocks_per_cu = static_cast<uint32_t>(std::max(bounce_blocks, 1));
+    if (c->scene.nodes4) { // spill area of the four-wide traversal's stack: at most 3 pushes per level
+        const uint32_t need = 3u * (c->depth4 + 1u);
+        const uint32_t spill_entries = need > kStack4Lds ? need - kStack4Lds : 1u;
+        c->scene.spill_stride = cus * std::max(c->blocks_per_cu, c->bounce_blocks_per_cu) * static_cast<uint32_t>(kExtendThreads);
+        CREATE_HIP(dmalloc(&c->d_stack_spill, static_cast<size_t>(spill_entries) * c->scene.spill_stride));
+        c->scene.stack_spill = c->d_stack_spill;
+    }
     c->accumulate_grid = std::min<uint32_t>((3u * c->pixel_capacity / 4u + 255u) / 256u, cus * 8u);
     if (c->accumulate_grid == 0) c->accumulate_grid = 1;
     CREATE_HIP(hipStreamSynchronize(c->stream));
@@ -843,7 +921,7 @@ void wfpt_destroy(wfpt_ctx *c) {
                     c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->d_shade_rec, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera,
-                    c->d_nodes, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,
+                    c->d_nodes, c->d_nodes4, c->d_stack_spill, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,
                     c->d_materials};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

@@ -106,7 +106,27 @@ struct SceneDev {
     uint32_t lds_scene;           // 1: nodes + primitives + parents are staged in LDS by extend
     uint32_t lds_bytes;           // dynamic LDS the extend kernel needs for this scene
     uint32_t depth;               // levels below the root (validated <= kMaxTrailDepth)
+    // HBM-resident scenes: the binary tree collapsed into four-wide nodes (128 B each); null = walk
+    // the binary tree. Stack entries beyond the LDS column spill to `stack_spill`, entry k of global thread g at
+    // [k * spill_stride + g].
+    const float4 *nodes4;
+    uint32_t *stack_spill;
+    uint32_t spill_stride;
 };
+
+// Four-wide node: the boxes of up to four children in SoA rows, then the child words. A child word is the index of
+// a Node4 (inner child), kLeafFlag | count << 28 | first primitive (leaf child) or kEmptyChild. 128 bytes = one L2 line:
+// a random 128-byte record costs the memory system what a random 64-byte record costs (tools/microbench_node_fetch.hip),
+// and a four-wide tree needs about half the visits of the binary one.
+struct Node4 {
+    float min_x[4], min_y[4], min_z[4], max_x[4], max_y[4], max_z[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "a four-wide node is one 128-byte line");
+constexpr uint32_t kLeafFlag = 0x80000000u, kEmptyChild = 0xffffffffu;
+constexpr uint32_t kLeafCountShift = 28, kLeafMaxCount = 6, kLeafFirstMask = (1u << kLeafCountShift) - 1u; // count 7 would make an all-ones word possible
+constexpr uint32_t kStack4Lds = 16; // stack entries of the four-wide traversal kept in LDS (per lane)
 
 struct CameraDev {
     wfpt_gpu_camera cam;

@@ -224,6 +224,7 @@ __device__ __forceinline__ void keep4(const float4 &a, const float4 &b, const fl
 // trip to L2 / Infinity Cache before the popped node's own children can be requested. 8 entries cover 99.9 % of the
 // inner visits of the 1 M-triangle scene (oracle model).
 constexpr uint32_t kStackDepth = 8;
+static_assert(kStack4Lds <= 2u * kStackDepth, "the four-wide traversal's LDS column reuses the binary variant's stack area");
 constexpr uint32_t kMetaCountBits = 6; // packed fields: left_first << 6 | prim_count; 0xffffffff = does not fit, re-read
 
 template <typename Trail, typename ParentT, uint32_t STACK_DEPTH = 0>
@@ -387,6 +388,88 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     return nearest < 1e30f; // ex:157
 }
 
+// ---- four-wide traversal for HBM-resident scenes (build extension) ----------------------------
+// The closest hit does not depend on the order in which nodes are visited (only on which primitives pass the exact
+// test; equal-t ties between different primitives aside), so for scenes whose tree lives in HBM / Infinity Cache the
+// binary tree is collapsed into four-wide nodes at wfpt_create: one 128-byte fetch tests four boxes. The box test is
+// the reference's arithmetic (hit_bvh_node: (b - o) * inv, exact); skipping the collapsed level is safe because a
+// child box lies inside its parent's and the test is monotone in the box planes, so whenever a grandchild passes its
+// skipped parent would have passed too. Children are visited nearest first; the others go on a per-lane stack (LDS
+// column, spilling to global memory past kStack4Lds entries).
+struct Stack4 {
+    uint32_t *lds;    // this lane's LDS column: entry k at lds[k * kExtendThreads]
+    uint32_t *spill;  // this thread's global column: entry k (>= kStack4Lds) at spill[(k - kStack4Lds) * stride]
+    uint32_t stride;
+    uint32_t sp = 0;
+    __device__ __forceinline__ void push(uint32_t w) {
+        if (sp < kStack4Lds) lds[sp * kExtendThreads] = w;
+        else spill[static_cast<size_t>(sp - kStack4Lds) * stride] = w;
+        sp += 1;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        sp -= 1;
+        return sp < kStack4Lds ? lds[sp * kExtendThreads] : spill[static_cast<size_t>(sp - kStack4Lds) * stride];
+    }
+};
+
+__device__ __forceinline__ void order2(float &ta, uint32_t &wa, float &tb, uint32_t &wb) { // afterwards ta <= tb
+    const bool swap = ta > tb;
+    const float t0 = swap ? tb : ta, t1 = swap ? ta : tb;
+    const uint32_t w0 = swap ? wb : wa, w1 = swap ? wa : wb;
+    ta = t0; tb = t1; wa = w0; wb = w1;
+}
+
+template <int PRIM>
+__device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *prim_geom, Stack4 st, float ox, float oy, float oz, float dx,
+                                           float dy, float dz, uint32_t max_steps, float &t_out, uint32_t &prim_out) {
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float a = (dx * dx + dy * dy) + dz * dz;
+    float nearest = 1e30f;
+    uint32_t best = 0xffffffffu;
+    uint32_t cur = 0; // node 0 is the root's four-wide node (the root's own box is never tested, ex:84)
+    bool alive = true;
+    uint32_t budget = max_steps; // every node is visited at most once on a valid tree
+#ifdef WFPT_DEBUG_BUDGET
+    budget = WFPT_DEBUG_BUDGET;
+#endif
+    while (alive) {
+        while (alive && !(cur & kLeafFlag)) {
+            if (budget-- == 0) { alive = false; break; }
+            const float4 *nd = nodes4 + 8u * static_cast<size_t>(cur);
+            const float4 mnx = nd[0], mny = nd[1], mnz = nd[2], mxx = nd[3], mxy = nd[4], mxz = nd[5];
+            const float4 cw = nd[6];
+            uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z), w3 = __float_as_uint(cw.w);
+            float t0 = hit_bvh_node(make_float4(mnx.x, mny.x, mnz.x, 0.f), make_float4(mxx.x, mxy.x, mxz.x, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            float t1 = hit_bvh_node(make_float4(mnx.y, mny.y, mnz.y, 0.f), make_float4(mxx.y, mxy.y, mxz.y, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            float t2 = hit_bvh_node(make_float4(mnx.z, mny.z, mnz.z, 0.f), make_float4(mxx.z, mxy.z, mxz.z, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            float t3 = hit_bvh_node(make_float4(mnx.w, mny.w, mnz.w, 0.f), make_float4(mxx.w, mxy.w, mxz.w, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            // a child is entered when the ray meets its box no farther than the nearest hit (hit_bvh_node returns 1e30 otherwise)
+            t0 = (w0 == kEmptyChild || t0 >= 1e30f) ? 2e30f : t0;
+            t1 = (w1 == kEmptyChild || t1 >= 1e30f) ? 2e30f : t1;
+            t2 = (w2 == kEmptyChild || t2 >= 1e30f) ? 2e30f : t2;
+            t3 = (w3 == kEmptyChild || t3 >= 1e30f) ? 2e30f : t3;
+            order2(t0, w0, t1, w1); order2(t2, w2, t3, w3); order2(t0, w0, t2, w2); order2(t1, w1, t3, w3); order2(t1, w1, t2, w2);
+            if (t0 >= 2e30f) { // nothing to enter
+                if (st.sp == 0) alive = false; else cur = st.pop();
+            } else {
+                if (t3 < 2e30f) st.push(w3); // farthest first, so the nearer ones pop first
+                if (t2 < 2e30f) st.push(w2);
+                if (t1 < 2e30f) st.push(w1);
+                cur = w0;
+            }
+        }
+        if (alive && budget-- == 0) alive = false;
+        if (alive) { // leaf child: kLeafFlag | count << 28 | first
+            const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
+            for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+            if (st.sp == 0) alive = false; else cur = st.pop();
+        }
+    }
+    t_out = nearest;
+    prim_out = best;
+    return nearest < 1e30f;
+}
+
 // Persistent workgroups of 512 threads (8 waves): stage the scene in LDS once, then trace queue
 // segments of 512 rays handed out by an atomic ticket. A segment's hits / misses are compacted in
 // thread order into the matching segment of the hit / miss queues with wave64 ballots + mbcnt and one
@@ -467,7 +550,13 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
             if (LDS_SCENE)
                 hit = trace_ray<Trail, PRIM, uint16_t, 0>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
                                                           prim);
-            else
+            else if (a.scene.nodes4) {
+                Stack4 st;
+                st.lds = s_stack + threadIdx.x;
+                st.stride = a.scene.spill_stride;
+                st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
+                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
                                                                      s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
                                                                      a.scene.n_nodes, t, prim);
@@ -1050,7 +1139,13 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         if (live) {
             if (LDS_SCENE)
                 hit = trace_ray<Trail, PRIM, uint16_t, 0>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
-            else
+            else if (a.scene.nodes4) {
+                Stack4 st;
+                st.lds = L.stack + threadIdx.x;
+                st.stride = a.scene.spill_stride;
+                st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
+                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
                                                                      ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
         }
