@@ -162,7 +162,8 @@ typedef enum wfpt_stage {
     WFPT_STAGE_BOUNCE_FIRST = 9,  /* "bounce_first": generate_rays + extend of wavefront 0 */
     WFPT_STAGE_BOUNCE = 10,       /* "bounce": shade of wavefront b-1 + extend of wavefront b + miss_kernel of b-1 */
     WFPT_STAGE_BOUNCE_LAST = 11,  /* "bounce_last": shade + miss_kernel of the last wavefront */
-    WFPT_STAGE_COUNT = 12
+    WFPT_STAGE_COMPACT = 12,      /* "compact": scenes beyond LDS only -- dense per-ray results into the queues */
+    WFPT_STAGE_COUNT = 13
 } wfpt_stage;
 
 /* How shade keys its RNG (shade.wgsl:72 uses the dispatch's global_invocation_id):
@@ -179,8 +180,10 @@ enum {
     WFPT_FLAG_UNFUSED = 1u << 2,     /* device-resident loop runs the stage kernels one by one (extend, scan, shade,
                                         miss_kernel per wavefront) instead of one fused bounce launch per wavefront.
                                         Same images bit for bit; WFPT_FLAG_SPLIT_SHADE implies it. */
-    WFPT_FLAG_BINARY_BVH = 1u << 3   /* scenes too large for LDS: walk the caller's binary tree as it is instead of the
+    WFPT_FLAG_BINARY_BVH = 1u << 3,  /* scenes too large for LDS: walk the caller's binary tree as it is instead of the
                                         four-wide collapse built at wfpt_create (same hits; for comparisons) */
+    WFPT_FLAG_NO_REFILL = 1u << 4    /* scenes too large for LDS: lanes keep their ray until the whole 512-ray segment is
+                                        done (the fused bounce kernel) instead of taking new rays as they finish */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu
@@ -285,7 +288,10 @@ const char *wfpt_last_error(const wfpt_ctx *ctx);
  * frame), and writes the accumulated frame (3 floats per pixel, row-major, width * height pixels) to host memory at
  * `rgb`. params->tile_rank / tile_world / max_pixels are ignored. With chunks > 1 params->rng_mode must be
  * WFPT_RNG_PIXEL (the dispatch-keyed RNG of shade.wgsl:72 depends on a ray's queue position, hence on the cut); the
- * frame is then bit-identical to the unchunked WFPT_RNG_PIXEL render. Blocking. */
+ * frame is then bit-identical to the unchunked WFPT_RNG_PIXEL render as long as the loop-exit test of path_tracer.rs:332
+ * (`misses < miss_floor`), which every chunk applies to its OWN miss count, fires in no chunk before it would for the
+ * whole frame -- with miss_floor = 0 (wavefront limit only) it never does and the image is independent of the cut.
+ * The same holds for contexts sharded with tile_rank / tile_world across GPUs. Blocking. */
 int wfpt_render_chunked(const wfpt_params *params,
                         const wfpt_sphere *spheres, uint32_t n_spheres,
                         const wfpt_material *materials, uint32_t n_materials,

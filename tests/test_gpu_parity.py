@@ -220,9 +220,17 @@ def test_tile_sharding_pixel_mode(gpu, orc):
     # the same behind the C ABI (wfpt_render_chunked): one call, frame assembled into the caller's buffer; 225 % 8 != 0
     cc = W.CameraController(W.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
     rp = W.RenderParameters(cc, (w, h))
-    for chunks in (1, 5, 29):  # 29 bands: one band per chunk
+    for chunks in (1, 5):
         scene = W.Scene.book_one_final(1)  # fresh: building the BVH reorders the spheres in place
         assert_bit_equal(W.render_chunked(scene, rp, spp, chunks, max_wavefronts=4), ref, f"wfpt_render_chunked, {chunks} chunks")
+    # The loop-exit test `misses < miss_floor` (path_tracer.rs:332) sees each chunk's own miss count: with one band per chunk
+    # (29 chunks) some chunks fall below the reference's 128 although the whole frame does not. miss_floor = 0 leaves the
+    # wavefront limit as the only bound and makes the image independent of the cut.
+    nofloor = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL, miss_floor=0)
+    nofloor.render(spp)
+    assert_bit_equal(W.render_chunked(W.Scene.book_one_final(1), rp, spp, 29, max_wavefronts=4, miss_floor=0), nofloor.accumulated(),
+                     "wfpt_render_chunked, one band per chunk, miss_floor 0")
+    nofloor.close()
     with pytest.raises(W.WfptError):
         W.render_chunked(W.Scene.book_one_final(1), rp, spp, 3, max_wavefronts=4, rng_mode=W.RNG_DISPATCH)  # the dispatch-keyed RNG depends on the cut
     full.close()

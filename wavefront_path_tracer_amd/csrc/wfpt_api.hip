@@ -76,6 +76,7 @@ struct wfpt_ctx {
     int comm_rank = 0, comm_world = 1;
     float *gather_stage = nullptr; // root: [world - 1] slabs received from the peers
     float *gather_frame = nullptr; // root: assembled frame, whole bands (ceil(height / 8) * 8 rows)
+    float4 *rec_dense = nullptr; // HBM-resident scenes: per-ray results of the refill traversal, [batch][capacity][2]
     uint32_t classic_batch = 1; // slices of the stage-by-stage queues: batch_max when the loop runs unfused, else 1 (stage API)
     uint32_t bounce_blocks_per_cu = 1;
     bool fused = true;
@@ -391,6 +392,44 @@ BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb) 
     a.scene = c->scene;
     return a;
 }
+RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb) {
+    RefillArgs a{};
+    a.batch = batch_of(c, nb);
+    a.rec_in = c->rec_mem[in_parity];
+    a.dense_out = c->rec_dense;
+    a.in_hits = c->f_chunk_hits[in_parity];
+    a.in_hit_base = c->chunk_hit_base;
+    a.in_first_seg = c->first_seg;
+    a.image = c->image;
+    a.ctl = c->ctl;
+    a.camera = c->camera;
+    a.gx = c->tiles_x;
+    a.gy = c->tiles_y_local;
+    a.capacity = c->capacity;
+    a.rng_mode = c->p.rng_mode;
+    a.image_width = c->width;
+    a.tile = c->tile;
+    a.scene = c->scene;
+    return a;
+}
+CompactArgs compact_args(wfpt_ctx *c, int out_parity, uint32_t nb) {
+    CompactArgs a{};
+    a.batch = batch_of(c, nb);
+    a.dense_in = c->rec_dense;
+    a.rec_out = c->rec_mem[out_parity];
+    a.mq_out = c->f_mq[out_parity];
+    a.out_hits = c->f_chunk_hits[out_parity];
+    a.out_miss = c->f_chunk_miss[out_parity];
+    a.ctl = c->ctl;
+    a.capacity = c->capacity;
+    return a;
+}
+MissArgs fused_miss_args(wfpt_ctx *c, int parity, uint32_t nb) { // miss_kernel over the fused loop's miss queue of one wavefront
+    MissArgs a = miss_args(c, 0, &c->ctl->miss_n, c->capacity, nb);
+    a.mq = c->f_mq[parity];
+    a.chunk_miss = c->f_chunk_miss[parity];
+    return a;
+}
 uint32_t bounce_grid(const wfpt_ctx *c, uint32_t n) {
     // hit items + miss items never exceed 1.25 work items per segment
     const uint64_t items = (static_cast<uint64_t>(c->n_chunks_max) * 5u / 4u + 1u) * n;
@@ -423,6 +462,28 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     };
     c->cur = 0;
     const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
+    if (c->fused && c->rec_dense) {
+        // HBM-resident scene: traversal with dynamic lane refill. Per wavefront: (miss_kernel of the previous one) |
+        // refill-trace into dense per-ray records | compact into the queues | scan; then shade+miss of the last one.
+        const uint32_t grid = c->cus * c->bounce_blocks_per_cu;
+        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_refill(refill_args(c, 1, nb), kBounceFirst, grid, c->stream); }));
+        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+            const int par = static_cast<int>(b & 1u);
+            WFPT_HIP(c, timed(WFPT_STAGE_COMPACT, [&] { return launch_compact(compact_args(c, par, nb), c->n_chunks_max, c->stream); }));
+            WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
+                              [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par), c->stream); }));
+            if (b + 1 < c->p.max_wavefronts) {
+                WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] { return launch_miss(fused_miss_args(c, par, nb), consumer_grid(c, nb), c->stream); }));
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_refill(refill_args(c, par, nb), kBounceMiddle, grid, c->stream); }));
+            } else {
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceLast, bounce_grid(c, nb), c->stream); }));
+            }
+        }
+        WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
+                     return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
+                 }));
+        return WFPT_OK;
+    }
     if (c->fused) {
         // generate+extend | scan | (shade+extend+miss | scan) x (max_wavefronts - 1) | shade+miss | accumulate
         const uint32_t grid = bounce_grid(c, nb);
@@ -781,6 +842,8 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
             c->scene.nodes4 = c->d_nodes4;
         }
     }
+    if (c->fused && c->scene.nodes4 && !(params->flags & WFPT_FLAG_NO_REFILL))
+        CREATE_HIP(dmalloc(&c->rec_dense, 2 * nb_all * c->capacity));
     c->scene.nodes = c->d_nodes;
     c->scene.pair_parent = c->d_pair_parent;
     c->scene.pair_parent32 = c->d_pair_parent32;
@@ -916,7 +979,7 @@ void wfpt_destroy(wfpt_ctx *c) {
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
-    void *bufs[] = {c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
+    void *bufs[] = {c->rec_dense, c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
                     c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg,
                     c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->d_shade_rec, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,

@@ -245,7 +245,8 @@ template <typename Prims> class BvhBuilder {
 
 const char *const kStageNames[WFPT_STAGE_COUNT] = {"generate_rays",    "extend",      "shade",           "miss_kernel",
                                                    "accumulate",       "shade_lambertian", "shade_metal", "shade_dielectric",
-                                                   "scan",             "bounce_first", "bounce",          "bounce_last"};
+                                                   "scan",             "bounce_first", "bounce",          "bounce_last",
+                                                   "compact"};
 
 } // namespace
 

@@ -225,6 +225,39 @@ struct BounceArgs {
     SceneDev scene;
 };
 
+// ---- HBM-resident scenes: traversal with dynamic lane refill. Rays of such scenes take very
+// different numbers of steps (1M-triangle soup: mean 188, p99 650), so a wave that keeps its 64 rays until the longest one
+// ends runs at 13-17 % lane utilisation. Here every wave is an independent worker: a lane that finishes its ray takes
+// the next ray index from a global cursor (in groups, one atomic per group), sets the ray up itself (generate_rays, or
+// shade of hit h of the previous wavefront) and traces it. Results go to a DENSE per-ray array; `compact_kernel` then
+// builds the segment-compacted path-record / miss queues in ray order, so everything downstream (scan, RNG keying by
+// queue position, the next wavefront) sees exactly the queues the fused bounce kernel would have written.
+constexpr uint32_t kDenseMiss = 0xffffffffu, kDenseInactive = 0xfffffffeu; // primitive word of a dense record that is not a hit
+constexpr uint32_t kRefillIdle = 16; // refill when at least this many lanes of a wave are idle
+
+struct RefillArgs {
+    Batch batch;
+    const float4 *rec_in;  // compact hit records of the previous wavefront
+    float4 *dense_out;     // [batch][capacity][2]: (p | pixel), (d | prim or kDenseMiss / kDenseInactive), indexed by ray
+    const uint32_t *in_hits, *in_hit_base, *in_first_seg;
+    float *image;
+    Control *ctl;
+    const CameraDev *camera;
+    uint32_t gx, gy, capacity, rng_mode, image_width;
+    Tiling tile;
+    SceneDev scene;
+};
+
+struct CompactArgs {
+    Batch batch;
+    const float4 *dense_in;
+    float4 *rec_out;
+    MissQueue mq_out;
+    uint32_t *out_hits, *out_miss;
+    const Control *ctl; // n_in = rays of this wavefront
+    uint32_t capacity;
+};
+
 struct ShadeArgs {
     Batch batch;
     RayQueue q, ext;
@@ -273,6 +306,8 @@ hipError_t launch_generate(const GenerateArgs &a, hipStream_t s);
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s); // one workgroup per sample
 hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s);
+hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s);
+hipError_t launch_compact(const CompactArgs &a, uint32_t n_chunks, hipStream_t s);
 hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks);
 uint32_t bounce_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene);
 hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s);

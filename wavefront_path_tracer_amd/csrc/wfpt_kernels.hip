@@ -1186,6 +1186,209 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
 }
 
 // ================================================================================================
+// HBM-resident scenes: four-wide traversal with dynamic lane refill + dense results + compaction (see RefillArgs).
+// MODE kBounceFirst: ray G is slot G of generate_rays' numbering; kBounceMiddle: ray G is the extension ray of hit G of
+// the previous wavefront (shade runs at refill time, by the lane that takes the ray).
+// ================================================================================================
+#ifndef WFPT_REFILL_MIN_WAVES
+#define WFPT_REFILL_MIN_WAVES 8
+#endif
+template <int MODE, int PRIM>
+__global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_kernel(RefillArgs a) {
+    extern __shared__ float4 lds[];
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(lds);   // [kMaxBatch] rays of this wavefront per sample
+    uint32_t *s_first = s_n + kMaxBatch;                  // [kMaxBatch + 1] first global ray index of each sample
+    uint32_t *s_stack = s_first + kMaxBatch + 4;          // [kStack4Lds][kExtendThreads]
+    const uint32_t n_slots = a.gx * a.gy * 64u;
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
+            const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
+            s_n[smp] = n;
+            s_first[smp] = total;
+            total += n;
+        }
+        s_first[a.batch.n] = total;
+    }
+    __syncthreads();
+    const uint32_t total = s_first[a.batch.n];
+    if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n) a.ctl[threadIdx.x].n_in = umin(n_slots, a.capacity); // pt:313-316
+    if (total == 0) return;
+    const wfpt_frame_buffer fb0 = a.ctl->frame;
+    const uint32_t lane = lane_id();
+    Stack4 st;
+    st.lds = s_stack + threadIdx.x;
+    st.stride = a.scene.spill_stride;
+    st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
+    const float4 *nodes4 = a.scene.nodes4;
+
+    // per-lane ray and traversal state
+    bool alive = false;
+    uint32_t smp = 0, ray = 0, pixel_idx = 0, cur = 0, best = 0xffffffffu, budget = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, aa = 0, nearest = 1e30f;
+    bool more = true; // rays left at the cursor (wave-uniform)
+    for (;;) {
+        // ---------------- refill: idle lanes take the next rays (one atomic per group)
+        const unsigned long long idle = __ballot(!alive);
+        const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+        if (more && (n_idle >= kRefillIdle)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&a.ctl->ticket, n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            more = base + n_idle < total;
+            const uint32_t g = base + mbcnt(idle);
+            if (!alive && g < total) {
+                smp = 0;
+                while (g >= s_first[smp + 1]) ++smp;
+                ray = g - s_first[smp];
+                float *image = a.image + smp * a.batch.image_stride;
+                wfpt_frame_buffer fb = fb0;
+                fb.frame += smp;
+                bool ok = true;
+                if (MODE == kBounceFirst) { // generate_rays (gr:42-91), true-size semantics
+                    const uint32_t workgroup_index = ray >> 6, local_index = ray & 63u;
+                    const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
+                    const uint32_t id_x = wx * 8u + (local_index & 7u);
+                    const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
+                    ok = id_x < fb.width && id_y < fb.height;
+                    if (ok) {
+                        pixel_idx = id_x + id_y * fb.width;
+                        const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
+                        ox = pr.ox; oy = pr.oy; oz = pr.oz; dx = pr.dx; dy = pr.dy; dz = pr.dz;
+                        float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, fb.width, a.tile));
+                        px[0] = 1.0f; px[1] = 1.0f; px[2] = 1.0f;
+                    } else { // a lane outside the image: neither hit nor miss
+                        const size_t slot = smp * a.batch.queue_stride + ray;
+                        a.dense_out[2u * slot + 1u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kDenseInactive));
+                    }
+                } else { // shade (sh:56-156) of hit `ray` of the previous wavefront
+                    const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+                    const uint32_t n = s_n[smp], run = ray / kChunk, n_runs = (n + kChunk - 1) / kChunk;
+                    uint32_t lo = a.in_first_seg[co + run];
+                    uint32_t hi = run + 1 < n_runs ? a.in_first_seg[co + run + 1] : (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk - 1u;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (a.in_hit_base[co + mid] <= ray) lo = mid; else hi = mid - 1u;
+                    }
+                    const size_t slot = qo + static_cast<size_t>(lo) * kChunk + (ray - a.in_hit_base[co + lo]);
+                    const float4 ra = a.rec_in[2u * slot], rb = a.rec_in[2u * slot + 1u];
+                    pixel_idx = __float_as_uint(ra.w);
+                    const uint32_t prim = __float_as_uint(rb.w);
+                    const float4 rec0 = a.scene.shade_rec[3u * prim], rec1 = a.scene.shade_rec[3u * prim + 1u], rec2 = a.scene.shade_rec[3u * prim + 2u];
+                    float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
+                    const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
+                    const uint32_t rng = shade_rng(a.rng_mode, ray, a.ctl[smp].shade_gx, pixel_idx, fb);
+                    const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), a.scene.prim_kind);
+                    ox = ra.x; oy = ra.y; oz = ra.z;
+                    dx = ext.x; dy = ext.y; dz = ext.z;
+                    px[0] = thr_r * rec1.x; px[1] = thr_g * rec1.y; px[2] = thr_b * rec1.z;
+                }
+                if (ok) {
+                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                    aa = (dx * dx + dy * dy) + dz * dz;
+                    nearest = 1e30f; best = 0xffffffffu; cur = 0; st.sp = 0; budget = a.scene.n_nodes;
+                    alive = true;
+                }
+            }
+        }
+        if (__ballot(alive) == 0) {
+            if (!more) break;
+            continue; // everything fetched so far was outside the image: fetch again
+        }
+        // ---------------- one round of the four-wide traversal (trace_ray4's loop body) for the lanes that hold a ray
+        bool fin = false;
+        while (alive && !fin && !(cur & kLeafFlag)) {
+            if (budget-- == 0) { fin = true; break; }
+            const float4 *nd = nodes4 + 8u * static_cast<size_t>(cur);
+            const float4 mnx = nd[0], mny = nd[1], mnz = nd[2], mxx = nd[3], mxy = nd[4], mxz = nd[5];
+            const float4 cw = nd[6];
+            uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z), w3 = __float_as_uint(cw.w);
+            float t0 = hit_bvh_node(make_float4(mnx.x, mny.x, mnz.x, 0.f), make_float4(mxx.x, mxy.x, mxz.x, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            float t1 = hit_bvh_node(make_float4(mnx.y, mny.y, mnz.y, 0.f), make_float4(mxx.y, mxy.y, mxz.y, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            float t2 = hit_bvh_node(make_float4(mnx.z, mny.z, mnz.z, 0.f), make_float4(mxx.z, mxy.z, mxz.z, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            float t3 = hit_bvh_node(make_float4(mnx.w, mny.w, mnz.w, 0.f), make_float4(mxx.w, mxy.w, mxz.w, 0.f), ox, oy, oz, ix, iy, iz, nearest);
+            t0 = (w0 == kEmptyChild || t0 >= 1e30f) ? 2e30f : t0;
+            t1 = (w1 == kEmptyChild || t1 >= 1e30f) ? 2e30f : t1;
+            t2 = (w2 == kEmptyChild || t2 >= 1e30f) ? 2e30f : t2;
+            t3 = (w3 == kEmptyChild || t3 >= 1e30f) ? 2e30f : t3;
+            order2(t0, w0, t1, w1); order2(t2, w2, t3, w3); order2(t0, w0, t2, w2); order2(t1, w1, t3, w3); order2(t1, w1, t2, w2);
+            if (t0 >= 2e30f) {
+                if (st.sp == 0) fin = true; else cur = st.pop();
+            } else {
+                if (t3 < 2e30f) st.push(w3);
+                if (t2 < 2e30f) st.push(w2);
+                if (t1 < 2e30f) st.push(w1);
+                cur = w0;
+            }
+        }
+        if (alive && !fin) { // at a leaf child
+            if (budget-- == 0) {
+                fin = true;
+            } else {
+                const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
+                for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(a.scene.prim_geom, first + i, ox, oy, oz, dx, dy, dz, aa, nearest, best);
+                if (st.sp == 0) fin = true; else cur = st.pop();
+            }
+        }
+        if (alive && fin) { // the ray is done: dense record in ray order (p = o + t d as shade reads it, sh:91)
+            const size_t slot = smp * a.batch.queue_stride + ray;
+            const bool hit = nearest < 1e30f; // ex:157
+            a.dense_out[2u * slot] = make_float4(ox + nearest * dx, oy + nearest * dy, oz + nearest * dz, __uint_as_float(pixel_idx));
+            a.dense_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(hit ? best : kDenseMiss));
+            alive = false;
+        }
+    }
+}
+
+// dense per-ray results -> the segment-compacted path-record and miss queues of the fused loop, in ray order
+__global__ __launch_bounds__(kExtendThreads) void compact_kernel(CompactArgs a) {
+    __shared__ uint32_t s_cnt[2][kExtendWaves];
+    const uint32_t smp = blockIdx.y, chunk = blockIdx.x;
+    const uint32_t n = umin(a.ctl[smp].n_in, a.capacity);
+    if (chunk * kChunk >= n) return;
+    const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+    const uint32_t idx = chunk * kChunk + threadIdx.x;
+    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, __uint_as_float(kDenseInactive));
+    if (idx < n) {
+        rb = a.dense_in[2u * (qo + idx) + 1u];
+        if (__float_as_uint(rb.w) != kDenseInactive) ra = a.dense_in[2u * (qo + idx)];
+    }
+    const uint32_t prim = __float_as_uint(rb.w);
+    const bool hit = prim < kDenseInactive, miss = prim == kDenseMiss;
+    const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_cnt[0][wave] = static_cast<uint32_t>(__popcll(hit_mask));
+        s_cnt[1][wave] = static_cast<uint32_t>(__popcll(miss_mask));
+    }
+    __syncthreads();
+    uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kExtendWaves; ++w) {
+        const uint32_t hc = s_cnt[0][w], mc = s_cnt[1][w];
+        hit_before += (w < wave) ? hc : 0u;
+        miss_before += (w < wave) ? mc : 0u;
+        hit_total += hc;
+        miss_total += mc;
+    }
+    const size_t seg = qo + static_cast<size_t>(chunk) * kChunk;
+    if (hit) {
+        const size_t slot = seg + hit_before + mbcnt(hit_mask);
+        a.rec_out[2u * slot] = ra;
+        a.rec_out[2u * slot + 1u] = rb;
+    }
+    if (miss) {
+        const size_t slot = seg + miss_before + mbcnt(miss_mask);
+        a.mq_out.dy()[slot] = rb.y;
+        a.mq_out.pixel()[slot] = __float_as_uint(ra.w);
+    }
+    if (threadIdx.x == 0) {
+        a.out_hits[co + chunk] = hit_total;
+        a.out_miss[co + chunk] = miss_total;
+    }
+}
+
+// ================================================================================================
 // accumulate (ac:4-17): pure streaming, 16 B per lane
 // ================================================================================================
 __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
@@ -1375,6 +1578,25 @@ hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks) {
 hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(bounce_variant(a.scene, mode), dim3(grid), dim3(kExtendThreads), bounce_dynamic_lds(a.scene, mode), s, a);
+    return hipGetLastError();
+}
+
+namespace {
+constexpr uint32_t kRefillLdsBytes = 4u * (2u * kMaxBatch + 4u + kStack4Lds * kExtendThreads);
+}
+
+hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s) {
+    if (grid == 0) return hipSuccess;
+    using Fn = void (*)(RefillArgs);
+    const Fn fn = a.scene.prim_kind == 0 ? (mode == kBounceFirst ? refill_kernel<kBounceFirst, 0> : refill_kernel<kBounceMiddle, 0>)
+                                         : (mode == kBounceFirst ? refill_kernel<kBounceFirst, 1> : refill_kernel<kBounceMiddle, 1>);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kExtendThreads), kRefillLdsBytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const CompactArgs &a, uint32_t n_chunks, hipStream_t s) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_kernel, dim3(n_chunks, a.batch.n), dim3(kExtendThreads), 0, s, a);
     return hipGetLastError();
 }
 
