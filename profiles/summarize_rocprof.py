@@ -25,6 +25,7 @@ import shutil
 import sys
 
 NAMES = [("bounce_kernel<0", "bounce_first"), ("bounce_kernel<1", "bounce"), ("bounce_kernel<2", "bounce_last"),
+         ("refill_kernel<0", "bounce_first"), ("refill_kernel<1", "bounce"), ("compact_kernel", "compact"),
          ("extend_kernel", "extend"), ("shade_kernel", "shade"), ("miss_kernel", "miss_kernel"), ("scan_kernel", "scan"),
          ("generate_rays_kernel", "generate_rays"), ("accumulate_kernel", "accumulate")]
 
@@ -56,7 +57,7 @@ def main():
     line = json.load(open(base + "stats.json"))
     json.dump(line, open(os.path.join(here, f"{rnd}_bench_line_{scene}_{variant}.json"), "w"), indent=1)
     out = {}
-    for d in ("fetch", "write", "sq", "sq2", "tcc"):
+    for d in ("fetch", "write", "sq", "sq2", "tcc", "tcp"):
         for p in glob.glob(base + d + "/*/*_counter_collection.csv"):
             for k, counters in pmc(p).items():
                 for c, v in counters.items():
@@ -87,13 +88,29 @@ def main():
                     f"({batches} samples in flight); FETCH_SIZE x calibration (gfx950 reports half the bytes of wide reads; "
                     "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE exact. bench.py scales "
                     "hbm_bytes_per_algorithmic_byte by its own run's algorithmic bytes per launch."})
+    # average duration of the dominant kernel in the UNPROFILED-counter pass (rocprofv3 --kernel-trace --stats)
+    avg_ns = None
+    if stats:
+        needle = {"bounce": ("bounce_kernel<1", "refill_kernel<1"), "extend": ("extend_kernel",)}[dom]
+        tot = cnt = 0.0
+        for r in csv.DictReader(open(stats[0])):
+            if any(n in r["Name"] for n in needle):
+                tot += float(r["TotalDurationNs"]); cnt += float(r["Calls"])
+        avg_ns = tot / cnt if cnt else None
+        summary["avg_launch_us_stats_pass"] = avg_ns / 1e3 if avg_ns else None
     if "SQ_ACTIVE_INST_VALU" in k and "GRBM_GUI_ACTIVE" in k:
-        # a wave64 fp32 instruction occupies a SIMD's 32 lanes for 2 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks
-        busy = k["SQ_ACTIVE_INST_VALU"]["mean"] * 2.0 / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
         lanes = k["SQ_THREAD_CYCLES_VALU"]["mean"] / k["SQ_ACTIVE_INST_VALU"]["mean"]
-        summary["secondary"] = {"valu_busy": round(busy, 4), "lanes_per_valu_instruction": round(lanes, 2),
+        summary["secondary"] = {"lanes_per_valu_instruction": round(lanes, 2),
                                 "valu_insts_per_launch": k["SQ_INSTS_VALU"]["mean"], "salu_insts_per_launch": k["SQ_INSTS_SALU"]["mean"],
                                 "lds_insts_per_launch": k["SQ_INSTS_LDS"]["mean"]}
+        if avg_ns:
+            # What bounds the traversal is wave64 VALU ISSUE. tools/microbench_valu.hip (profiles/r02_microbench_valu.txt): a SIMD
+            # of this chip sustains one independent v_fma_f32 per 1.26 ns with 8 waves resident (3.0 cycles at the nominal
+            # 2.4 GHz: the clock drops under an all-VALU load), 1.38-1.46 ns for compare + select mixes.
+            rate = k["SQ_INSTS_VALU"]["mean"] / 1024.0 / avg_ns  # wave instructions per ns per SIMD
+            summary["secondary"]["valu_issue_per_ns_per_simd"] = round(rate, 4)
+            summary["secondary"]["valu_issue_ceiling_per_ns_per_simd"] = 0.792
+            summary["secondary"]["valu_issue_frac"] = round(rate / 0.792, 4)
         if "SQ_WAIT_ANY" in k and "SQ_WAVE_CYCLES" in k:
             summary["secondary"]["wait_any_frac"] = round(k["SQ_WAIT_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)
             summary["secondary"]["wait_inst_any_frac"] = round(k["SQ_WAIT_INST_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)

@@ -204,7 +204,10 @@ struct ScanArgs {
 constexpr int kBounceFirst = 0;  // generate_rays -> extend                 (wavefront 0)
 constexpr int kBounceMiddle = 1; // shade -> extend, miss_kernel            (wavefronts 1 .. max-1)
 constexpr int kBounceLast = 2;   // shade (throughput only), miss_kernel    (after the last extend)
-constexpr int kMissSegsPerItem = 4; // miss work item = this many input segments
+#ifndef WFPT_MISS_SEGS
+#define WFPT_MISS_SEGS 16
+#endif
+constexpr int kMissSegsPerItem = WFPT_MISS_SEGS; // miss work item = this many input segments
 
 struct BounceArgs {
     Batch batch;

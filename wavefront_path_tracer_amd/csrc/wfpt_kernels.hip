@@ -1046,11 +1046,13 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             const uint32_t n_segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
             const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
             float *image = a.image + smp * a.batch.image_stride;
-            for (uint32_t k = 0; k < kMissSegsPerItem; ++k) {
+            // one segment per wave at a time: the eight waves keep eight independent load -> read-modify-write chains in flight
+            for (uint32_t k = wave; k < kMissSegsPerItem; k += kExtendWaves) {
                 const uint32_t seg = first_seg + k;
                 if (seg >= n_segs) break;
-                if (threadIdx.x < a.in_miss[co + seg]) {
-                    const size_t slot = qo + static_cast<size_t>(seg) * kChunk + threadIdx.x;
+                const uint32_t count = a.in_miss[co + seg];
+                for (uint32_t r = lane; r < count; r += 64u) {
+                    const size_t slot = qo + static_cast<size_t>(seg) * kChunk + r;
                     const float dy = a.mq_in.dy()[slot]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
                     const uint32_t pixel_idx = a.mq_in.pixel()[slot];
                     const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
