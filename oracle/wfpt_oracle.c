@@ -926,13 +926,16 @@ void orc_ray_rounds(orc_ctx *c, uint32_t n, uint8_t *segs, uint8_t *n_leaves) {
  * (Q = 0: a lane that reaches a leaf waits for the leaf phase, the schedule extend_kernel uses). A lane with a free
  * slot notes the leaf, pops and keeps traversing with its `nearest` not yet updated (speculative: visits more nodes,
  * results unchanged); the leaf phase runs when no lane can make an inner step and tests one noted leaf per lane and
- * pass. out[0] = inner-loop iterations summed over waves, [1] = leaf passes, [2] = inner visits (lane-steps),
+ * pass; Q's bits 8.. optionally hold a threshold T: the inner phase also ends once T lanes wait at a leaf.
+ * out[0] = inner-loop iterations summed over waves, [1] = leaf passes, [2] = inner visits (lane-steps),
  * [3] = leaf tests, [4] = waves. */
 typedef struct { orc_bvh_node node; orc_bvh_node stack[ORC_MAX_STACK]; uint32_t sp; float nearest; int done; int at_leaf;
                  uint32_t q[8]; uint32_t nq; } sim_lane;
 static void sim_pop(sim_lane *l) { if (l->sp == 0) l->done = 1; else l->node = l->stack[--l->sp]; }
 void orc_sim_postpone(orc_ctx *c, uint32_t n, uint32_t Q, uint64_t out[8]) {
     uint64_t iters = 0, passes = 0, visits = 0, tests = 0, waves = 0;
+    const uint32_t T = Q >> 8; /* optional: the inner phase also ends once T lanes wait at a leaf (0 = never) */
+    Q &= 0xffu;
     if (Q > 8) Q = 8;
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : iters, passes, visits, tests, waves)
     for (int64_t w0 = 0; w0 < (int64_t)n; w0 += 64) {
@@ -971,6 +974,11 @@ void orc_sim_postpone(orc_ctx *c, uint32_t n, uint32_t Q, uint64_t out[8]) {
                 }
                 if (!any) break;
                 iters++;
+                if (T) {
+                    uint32_t waiting = 0;
+                    for (int i = 0; i < nl; i++) waiting += (!L[i].done && L[i].at_leaf == 1);
+                    if (waiting >= T) break;
+                }
             }
             /* leaf phase: every lane tests its noted leaves (one per pass) and the leaf it waits at */
             int alive = 0;
