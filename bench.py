@@ -54,6 +54,7 @@ def parse():
                     help="auto: dispatch (reference-faithful) on 1 GPU, pixel (shard-invariant) on N > 1")
     ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-lds-scene", action="store_true", help="experiment: traverse the scene from HBM / L2 although it fits LDS")
     ap.add_argument("--no-refill", action="store_true", help="mesh scene: fused bounce kernel (lanes keep their ray) instead of dynamic lane refill")
     ap.add_argument("--binary-bvh", action="store_true", help="mesh scene: walk the binary tree instead of the four-wide collapse")
     ap.add_argument("--unfused", action="store_true", help="run the stage kernels one by one (extend, scan, shade, miss_kernel per wavefront)")
@@ -159,7 +160,7 @@ def main():
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
              (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0) |
-             (W.FLAG_NO_REFILL if args.no_refill else 0))
+             (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0))
     # samples in flight per launch: 32 at N=1 (16 -> 32 -> 64: 13.5 -> 14.0 -> 14.1 Grays/s, mostly fewer scan launches);
     # each rank of N holds 1/N of the pixels, so scale it to keep launches as large
     batch = args.batch or min(64, 32 * world)
@@ -300,6 +301,8 @@ def main():
             variant += "_binary"
         if args.no_refill:
             variant += "_norefill"
+        if args.no_lds_scene:
+            variant += "_nolds"
         pmc = load_pmc(args.scene, variant)
         # PMC traffic is a property of (scene, loop variant): the profile stores HBM bytes per algorithmic byte of the
         # same kernel on the same workload, scaled here by this run's algorithmic bytes per launch; null without a profile

@@ -182,8 +182,10 @@ enum {
                                         Same images bit for bit; WFPT_FLAG_SPLIT_SHADE implies it. */
     WFPT_FLAG_BINARY_BVH = 1u << 3,  /* scenes too large for LDS: walk the caller's binary tree as it is instead of the
                                         four-wide collapse built at wfpt_create (same hits; for comparisons) */
-    WFPT_FLAG_NO_REFILL = 1u << 4    /* scenes too large for LDS: lanes keep their ray until the whole 512-ray segment is
+    WFPT_FLAG_NO_REFILL = 1u << 4,   /* scenes too large for LDS: lanes keep their ray until the whole 512-ray segment is
                                         done (the fused bounce kernel) instead of taking new rays as they finish */
+    WFPT_FLAG_NO_LDS_SCENE = 1u << 5 /* treat the scene as too large for LDS even if it fits (experiments, tests of the
+                                        HBM-resident traversal on small scenes) */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu

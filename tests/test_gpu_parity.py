@@ -662,3 +662,42 @@ def test_wavefront_totals(gpu, orc):
         assert np.array_equal(pt.wavefront_totals().sum(axis=0), pt.totals())
         pt.close()
     o.close()
+
+
+@pytest.mark.parametrize("flags", ["NO_LDS_SCENE", "NO_LDS_SCENE|NO_REFILL", "NO_LDS_SCENE|BINARY_BVH", "NO_LDS_SCENE|UNFUSED"])
+def test_sphere_scene_through_the_hbm_traversal(gpu, orc, flags):
+    """The traversals built for scenes beyond LDS (four-wide collapsed tree with and without lane refill, binary tree from
+    global memory) on the SPHERE scene, which normally lives in LDS: same image, tables and totals as the oracle."""
+    W = gpu
+    fl = 0
+    for name in flags.split("|"):
+        fl |= getattr(W, "FLAG_" + name)
+    w, h, spp, bounces = 200, 123, 3, 6
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+    want = o.render(spp)
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, flags=fl, batch=2)
+    pt.render(spp)
+    assert_bit_equal(pt.accumulated(), want, flags)
+    assert np.array_equal(pt.totals(), o.totals()) and np.array_equal(pt.bounce_table(), o.bounce_table())
+    pt.close(); o.close()
+
+
+def test_gather_slabs_is_ordered_after_queued_torch_work(gpu):
+    """tiles.gather_slabs fills its send buffer on torch's stream and the context copies into it on its
+    own non-blocking stream. With a long kernel queued on torch's stream in front of the fill, a copy that did not wait for
+    that stream would be overwritten by the late fill; the slab must arrive intact."""
+    import torch
+    from wavefront_path_tracer_amd import tiles
+    W = gpu
+    w, h, spp = 400, 224, 2  # whole bands: an unsharded context holds exactly the slab gather_slabs asks for
+    dev = torch.device("cuda", 0)
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=4, rng_mode=W.RNG_PIXEL)
+    pt.render(spp)
+    ref = pt.accumulated()
+    a = torch.randn(4096, 4096, device=dev)
+    for _ in range(20):  # ~ tens of milliseconds of queued work on torch's current stream
+        a = a @ a
+        a = a / a.abs().max()
+    frame = tiles.gather_slabs(pt.copy_accumulated_to_device, 0, 1, w, h, device=dev, keep_on_device=True)
+    assert_bit_equal(frame.cpu().numpy().reshape(-1, 3), ref, "slab copied behind queued torch work")
+    pt.close()

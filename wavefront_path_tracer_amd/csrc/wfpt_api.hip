@@ -825,7 +825,7 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     // LDS variant when nodes + primitives + parents fit comfortably (>= 2 workgroups per CU); otherwise the
     // scene stays in HBM / Infinity Cache and extend reads it through L2.
     const uint32_t lds_need = extend_lds_bytes(n_nodes, n_spheres, prim_kind, true);
-    const bool lds_scene = n_nodes <= 65536u && lds_need <= 80u * 1024u;
+    const bool lds_scene = n_nodes <= 65536u && lds_need <= 80u * 1024u && !(params->flags & WFPT_FLAG_NO_LDS_SCENE);
     if (lds_scene) {
         std::vector<uint16_t> p16(pair_parent.begin(), pair_parent.end());
         CREATE_HIP(dmalloc(&c->d_pair_parent, p16.size()));
