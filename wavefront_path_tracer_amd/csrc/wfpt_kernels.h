@@ -236,7 +236,10 @@ struct BounceArgs {
 // builds the segment-compacted path-record / miss queues in ray order, so everything downstream (scan, RNG keying by
 // queue position, the next wavefront) sees exactly the queues the fused bounce kernel would have written.
 constexpr uint32_t kDenseMiss = 0xffffffffu, kDenseInactive = 0xfffffffeu; // primitive word of a dense record that is not a hit
-constexpr uint32_t kRefillIdle = 16; // refill when at least this many lanes of a wave are idle
+#ifndef WFPT_REFILL_IDLE
+#define WFPT_REFILL_IDLE 40
+#endif
+constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE; // refill when at least this many lanes of a wave are idle
 
 struct RefillArgs {
     Batch batch;
