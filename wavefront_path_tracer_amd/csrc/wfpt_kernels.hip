@@ -948,6 +948,50 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
     }
 }
 
+// shade (sh:56-156) of hit h of the previous wavefront, as the fused loop runs it: find the hit's path record (its
+// segment is the last one whose first hit is not after h, searched between the segments that hold the first hit of
+// this run of kChunk hits and of the next run: scan's first_seg table), multiply the pixel's throughput by the albedo
+// (sh:84-87) and, if SCATTER, produce the extension ray (origin = hit point, direction NOT normalised, sh:153-155).
+// Shared by the fused bounce kernel and the refill traversal.
+struct HitSource {
+    const float4 *rec_in;
+    const uint32_t *in_hit_base, *in_first_seg;
+    const Control *ctl;
+    float *image; // this sample's slice
+    const float4 *shade_rec;
+    size_t qo, co; // this sample's offsets into the record queue and the per-segment tables
+    uint32_t capacity, rng_mode, image_width, prim_kind;
+    Tiling tile;
+};
+template <bool SCATTER>
+__device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32_t n_hits, wfpt_frame_buffer fb, float &ox, float &oy,
+                                          float &oz, float &dx, float &dy, float &dz, uint32_t &pixel_idx) {
+    const uint32_t run = h / kChunk, n_runs = (n_hits + kChunk - 1) / kChunk;
+    uint32_t lo = s.in_first_seg[s.co + run];
+    uint32_t hi = run + 1 < n_runs ? s.in_first_seg[s.co + run + 1] : (umin(s.ctl->seg_n, s.capacity) + kChunk - 1) / kChunk - 1u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (s.in_hit_base[s.co + mid] <= h) lo = mid; else hi = mid - 1u;
+    }
+    const size_t slot = s.qo + static_cast<size_t>(lo) * kChunk + (h - s.in_hit_base[s.co + lo]);
+    const float4 ra = s.rec_in[2u * slot], rb = s.rec_in[2u * slot + 1u];
+    pixel_idx = __float_as_uint(ra.w);
+    const uint32_t prim = __float_as_uint(rb.w);
+    const float4 rec1 = s.shade_rec[3u * prim + 1u];
+    float *px = s.image + 3u * static_cast<size_t>(local_pixel(pixel_idx, s.image_width, s.tile));
+    const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
+    if (SCATTER) {
+        const float4 rec0 = s.shade_rec[3u * prim], rec2 = s.shade_rec[3u * prim + 2u];
+        const uint32_t rng = shade_rng(s.rng_mode, h, s.ctl->shade_gx, pixel_idx, fb);
+        const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), s.prim_kind);
+        ox = ra.x; oy = ra.y; oz = ra.z;
+        dx = ext.x; dy = ext.y; dz = ext.z;
+    }
+    px[0] = thr_r * rec1.x;
+    px[1] = thr_g * rec1.y;
+    px[2] = thr_b * rec1.z;
+}
+
 // ================================================================================================
 // Fused bounce kernel of the device-resident loop. The reference's loop runs, per wavefront, extend -> (host reads
 // the counters) -> shade -> miss_kernel -> copy extension rays back (pt:323-353). shade of wavefront b-1 and extend
@@ -1100,33 +1144,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             }
         } else if (live) {
             // ---------------- shade (sh:56-156) of hit h of the previous wavefront
-            // its segment: the last one whose first hit is not after h, searched between the segments that hold the
-            // first hit of this run and of the next run (scan's first_seg table)
-            const uint32_t n_runs = (n + kChunk - 1) / kChunk;
-            uint32_t lo = a.in_first_seg[co + seg_out];
-            uint32_t hi = seg_out + 1 < n_runs ? a.in_first_seg[co + seg_out + 1] : (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk - 1u;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1u) >> 1;
-                if (a.in_hit_base[co + mid] <= h) lo = mid; else hi = mid - 1u;
-            }
-            const size_t slot = qo + static_cast<size_t>(lo) * kChunk + (h - a.in_hit_base[co + lo]);
-            const float4 ra = a.rec_in[2u * slot], rb = a.rec_in[2u * slot + 1u];
-            pixel_idx = __float_as_uint(ra.w);
-            const uint32_t prim = __float_as_uint(rb.w);
-            const float4 rec1 = a.scene.shade_rec[3u * prim + 1u];
-            // sh:84-87: throughput *= albedo, for every material type
-            float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
-            const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
-            if (TRACE) {
-                const float4 rec0 = a.scene.shade_rec[3u * prim], rec2 = a.scene.shade_rec[3u * prim + 2u];
-                const uint32_t rng = shade_rng(a.rng_mode, h, a.ctl[smp].shade_gx, pixel_idx, fb);
-                const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), a.scene.prim_kind);
-                ox = ra.x; oy = ra.y; oz = ra.z; // sh:153-155: the extension ray starts at the hit point, direction NOT normalised
-                dx = ext.x; dy = ext.y; dz = ext.z;
-            }
-            px[0] = thr_r * rec1.x;
-            px[1] = thr_g * rec1.y;
-            px[2] = thr_b * rec1.z;
+            const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, image, a.scene.shade_rec, qo, co,
+                                a.capacity, a.rng_mode, a.image_width, a.scene.prim_kind, a.tile};
+            shade_hit<TRACE>(src, h, n, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
         }
         if (!TRACE) {
             __syncthreads();
@@ -1264,26 +1284,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                         a.dense_out[2u * slot + 1u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kDenseInactive));
                     }
                 } else { // shade (sh:56-156) of hit `ray` of the previous wavefront
-                    const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
-                    const uint32_t n = s_n[smp], run = ray / kChunk, n_runs = (n + kChunk - 1) / kChunk;
-                    uint32_t lo = a.in_first_seg[co + run];
-                    uint32_t hi = run + 1 < n_runs ? a.in_first_seg[co + run + 1] : (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk - 1u;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi + 1u) >> 1;
-                        if (a.in_hit_base[co + mid] <= ray) lo = mid; else hi = mid - 1u;
-                    }
-                    const size_t slot = qo + static_cast<size_t>(lo) * kChunk + (ray - a.in_hit_base[co + lo]);
-                    const float4 ra = a.rec_in[2u * slot], rb = a.rec_in[2u * slot + 1u];
-                    pixel_idx = __float_as_uint(ra.w);
-                    const uint32_t prim = __float_as_uint(rb.w);
-                    const float4 rec0 = a.scene.shade_rec[3u * prim], rec1 = a.scene.shade_rec[3u * prim + 1u], rec2 = a.scene.shade_rec[3u * prim + 2u];
-                    float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
-                    const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
-                    const uint32_t rng = shade_rng(a.rng_mode, ray, a.ctl[smp].shade_gx, pixel_idx, fb);
-                    const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), a.scene.prim_kind);
-                    ox = ra.x; oy = ra.y; oz = ra.z;
-                    dx = ext.x; dy = ext.y; dz = ext.z;
-                    px[0] = thr_r * rec1.x; px[1] = thr_g * rec1.y; px[2] = thr_b * rec1.z;
+                    const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, image, a.scene.shade_rec,
+                                        smp * a.batch.queue_stride, smp * a.batch.chunk_stride, a.capacity, a.rng_mode, a.image_width,
+                                        a.scene.prim_kind, a.tile};
+                    shade_hit<true>(src, ray, s_n[smp], fb, ox, oy, oz, dx, dy, dz, pixel_idx);
                 }
                 if (ok) {
                     ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
