@@ -391,10 +391,9 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
 // ---- four-wide traversal for HBM-resident scenes (build extension) ----------------------------
 // The closest hit does not depend on the order in which nodes are visited (only on which primitives pass the exact
 // test; equal-t ties between different primitives aside), so for scenes whose tree lives in HBM / Infinity Cache the
-// binary tree is collapsed into four-wide nodes at wfpt_create: one 128-byte fetch tests four boxes. The box test is
-// the reference's arithmetic (hit_bvh_node: (b - o) * inv, exact); skipping the collapsed level is safe because a
-// child box lies inside its parent's and the test is monotone in the box planes, so whenever a grandchild passes its
-// skipped parent would have passed too. Children are visited nearest first; the others go on a per-lane stack (LDS
+// binary tree is collapsed into four-wide nodes at wfpt_create: one 64-byte fetch tests four boxes (quantised, each
+// enclosing the true box: struct Node4). The box test is the reference's arithmetic (hit_bvh_node: (b - o) * inv) on
+// boxes that are never smaller than the reference's, so every primitive the reference would test is still tested. Children are visited nearest first; the others go on a per-lane stack (LDS
 // column, spilling to global memory past kStack4Lds entries).
 struct Stack4 {
     uint32_t *lds;    // this lane's LDS column: entry k at lds[k * kExtendThreads]
@@ -419,6 +418,42 @@ __device__ __forceinline__ void order2(float &ta, uint32_t &wa, float &tb, uint3
     ta = t0; tb = t1; wa = w0; wb = w1;
 }
 
+// One visit of a (quantised) four-wide node: dequantise the four child boxes (one fma per plane, the arithmetic the host
+// rounded against), test them with the reference's slab arithmetic, and return the children to enter sorted by entry
+// distance (t = 2e30: not entered).
+struct Visit4 {
+    float t0, t1, t2, t3;
+    uint32_t w0, w1, w2, w3;
+};
+__device__ __forceinline__ float ubyte(uint32_t word, int k) { return static_cast<float>((word >> (8 * k)) & 0xffu); }
+__device__ __forceinline__ Visit4 visit4(const float4 *nodes4, uint32_t cur, float ox, float oy, float oz, float ix, float iy, float iz,
+                                         float nearest) {
+    const float4 *nd = nodes4 + 4u * static_cast<size_t>(cur);
+    const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+    const uint32_t ex = __float_as_uint(a.w);
+    const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23),
+                sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
+    const uint32_t qlx = __float_as_uint(b.x), qly = __float_as_uint(b.y), qlz = __float_as_uint(b.z), qhx = __float_as_uint(b.w),
+                   qhy = __float_as_uint(c.x), qhz = __float_as_uint(c.y);
+    Visit4 v;
+    v.w0 = __float_as_uint(c.z); v.w1 = __float_as_uint(c.w); v.w2 = __float_as_uint(d.x); v.w3 = __float_as_uint(d.y);
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 lo = make_float4(fma_(ubyte(qlx, k), sx, a.x), fma_(ubyte(qly, k), sy, a.y), fma_(ubyte(qlz, k), sz, a.z), 0.0f);
+        const float4 hi = make_float4(fma_(ubyte(qhx, k), sx, a.x), fma_(ubyte(qhy, k), sy, a.y), fma_(ubyte(qhz, k), sz, a.z), 0.0f);
+        t[k] = hit_bvh_node(lo, hi, ox, oy, oz, ix, iy, iz, nearest);
+    }
+    // a child is entered when the ray meets its box no farther than the nearest hit (hit_bvh_node returns 1e30 otherwise)
+    v.t0 = (v.w0 == kEmptyChild || t[0] >= 1e30f) ? 2e30f : t[0];
+    v.t1 = (v.w1 == kEmptyChild || t[1] >= 1e30f) ? 2e30f : t[1];
+    v.t2 = (v.w2 == kEmptyChild || t[2] >= 1e30f) ? 2e30f : t[2];
+    v.t3 = (v.w3 == kEmptyChild || t[3] >= 1e30f) ? 2e30f : t[3];
+    order2(v.t0, v.w0, v.t1, v.w1); order2(v.t2, v.w2, v.t3, v.w3); order2(v.t0, v.w0, v.t2, v.w2); order2(v.t1, v.w1, v.t3, v.w3);
+    order2(v.t1, v.w1, v.t2, v.w2);
+    return v;
+}
+
 template <int PRIM>
 __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *prim_geom, Stack4 st, float ox, float oy, float oz, float dx,
                                            float dy, float dz, uint32_t max_steps, float &t_out, uint32_t &prim_out) {
@@ -435,33 +470,21 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
     while (alive) {
         while (alive && !(cur & kLeafFlag)) {
             if (budget-- == 0) { alive = false; break; }
-            const float4 *nd = nodes4 + 8u * static_cast<size_t>(cur);
-            const float4 mnx = nd[0], mny = nd[1], mnz = nd[2], mxx = nd[3], mxy = nd[4], mxz = nd[5];
-            const float4 cw = nd[6];
-            uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z), w3 = __float_as_uint(cw.w);
-            float t0 = hit_bvh_node(make_float4(mnx.x, mny.x, mnz.x, 0.f), make_float4(mxx.x, mxy.x, mxz.x, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            float t1 = hit_bvh_node(make_float4(mnx.y, mny.y, mnz.y, 0.f), make_float4(mxx.y, mxy.y, mxz.y, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            float t2 = hit_bvh_node(make_float4(mnx.z, mny.z, mnz.z, 0.f), make_float4(mxx.z, mxy.z, mxz.z, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            float t3 = hit_bvh_node(make_float4(mnx.w, mny.w, mnz.w, 0.f), make_float4(mxx.w, mxy.w, mxz.w, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            // a child is entered when the ray meets its box no farther than the nearest hit (hit_bvh_node returns 1e30 otherwise)
-            t0 = (w0 == kEmptyChild || t0 >= 1e30f) ? 2e30f : t0;
-            t1 = (w1 == kEmptyChild || t1 >= 1e30f) ? 2e30f : t1;
-            t2 = (w2 == kEmptyChild || t2 >= 1e30f) ? 2e30f : t2;
-            t3 = (w3 == kEmptyChild || t3 >= 1e30f) ? 2e30f : t3;
-            order2(t0, w0, t1, w1); order2(t2, w2, t3, w3); order2(t0, w0, t2, w2); order2(t1, w1, t3, w3); order2(t1, w1, t2, w2);
-            if (t0 >= 2e30f) { // nothing to enter
+            const Visit4 v = visit4(nodes4, cur, ox, oy, oz, ix, iy, iz, nearest);
+            if (v.t0 >= 2e30f) { // nothing to enter
                 if (st.sp == 0) alive = false; else cur = st.pop();
             } else {
-                if (t3 < 2e30f) st.push(w3); // farthest first, so the nearer ones pop first
-                if (t2 < 2e30f) st.push(w2);
-                if (t1 < 2e30f) st.push(w1);
-                cur = w0;
+                if (v.t3 < 2e30f) st.push(v.w3); // farthest first, so the nearer ones pop first
+                if (v.t2 < 2e30f) st.push(v.w2);
+                if (v.t1 < 2e30f) st.push(v.w1);
+                cur = v.w0;
             }
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf child: kLeafFlag | count << 28 | first
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+            for (uint32_t i = 0; i < count; ++i)
+                hit_prim<PRIM>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
     }
@@ -1313,26 +1336,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             if (budget-- == 0) {
                 fin = true;
             } else {
-            const float4 *nd = nodes4 + 8u * static_cast<size_t>(cur);
-            const float4 mnx = nd[0], mny = nd[1], mnz = nd[2], mxx = nd[3], mxy = nd[4], mxz = nd[5];
-            const float4 cw = nd[6];
-            uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z), w3 = __float_as_uint(cw.w);
-            float t0 = hit_bvh_node(make_float4(mnx.x, mny.x, mnz.x, 0.f), make_float4(mxx.x, mxy.x, mxz.x, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            float t1 = hit_bvh_node(make_float4(mnx.y, mny.y, mnz.y, 0.f), make_float4(mxx.y, mxy.y, mxz.y, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            float t2 = hit_bvh_node(make_float4(mnx.z, mny.z, mnz.z, 0.f), make_float4(mxx.z, mxy.z, mxz.z, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            float t3 = hit_bvh_node(make_float4(mnx.w, mny.w, mnz.w, 0.f), make_float4(mxx.w, mxy.w, mxz.w, 0.f), ox, oy, oz, ix, iy, iz, nearest);
-            t0 = (w0 == kEmptyChild || t0 >= 1e30f) ? 2e30f : t0;
-            t1 = (w1 == kEmptyChild || t1 >= 1e30f) ? 2e30f : t1;
-            t2 = (w2 == kEmptyChild || t2 >= 1e30f) ? 2e30f : t2;
-            t3 = (w3 == kEmptyChild || t3 >= 1e30f) ? 2e30f : t3;
-            order2(t0, w0, t1, w1); order2(t2, w2, t3, w3); order2(t0, w0, t2, w2); order2(t1, w1, t3, w3); order2(t1, w1, t2, w2);
-            if (t0 >= 2e30f) {
+            const Visit4 v = visit4(nodes4, cur, ox, oy, oz, ix, iy, iz, nearest);
+            if (v.t0 >= 2e30f) {
                 if (st.sp == 0) fin = true; else cur = st.pop();
             } else {
-                if (t3 < 2e30f) st.push(w3);
-                if (t2 < 2e30f) st.push(w2);
-                if (t1 < 2e30f) st.push(w1);
-                cur = w0;
+                if (v.t3 < 2e30f) st.push(v.w3);
+                if (v.t2 < 2e30f) st.push(v.w2);
+                if (v.t1 < 2e30f) st.push(v.w1);
+                cur = v.w0;
             }
             }
         }
@@ -1341,7 +1352,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 fin = true;
             } else {
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-                for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(a.scene.prim_geom, first + i, ox, oy, oz, dx, dy, dz, aa, nearest, best);
+                for (uint32_t i = 0; i < count; ++i)
+                    hit_prim<PRIM>(a.scene.prim_geom, first + i, ox, oy, oz, dx, dy, dz, aa, nearest, best);
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
