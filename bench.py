@@ -113,6 +113,14 @@ def cpu_baseline(args, rng_mode, gpu_frame=None):
     return out
 
 
+def baseline_metric():
+    """The headline metric string of BASELINE.json (committed next to this file), verbatim."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "Mrays/s (extend+shade) at 1920\u00d71080, 64 spp, 8 bounces; 1/2/4/8 GPU"
+
+
 def load_pmc(scene, variant):
     """Committed rocprofv3 --pmc summary of THIS workload and loop variant (profiles/r*_pmc_<scene>_<variant>.json,
     written by profiles/summarize_rocprof.py from the same bench command), newest round first; None if there is none."""
@@ -180,15 +188,38 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    gather_path = "none" if world == 1 else ("gloo through host memory (REHEARSAL)" if rehearsal else "RCCL send/recv to rank 0 behind the C ABI")
     if world > 1 and not rehearsal:
-        uid = [W.comm_unique_id() if rank == 0 else None]
+        # The RCCL bootstrap needs a socket interface; on one node the loopback always works (the data itself goes over xGMI)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        err = None
+        try:
+            uid = [W.comm_unique_id() if rank == 0 else None]
+        except W.WfptError as e:
+            uid, err = [None], str(e)
         dist.broadcast_object_list(uid, src=0)
-        pt.comm_init(uid[0], rank, world)  # collective: ncclCommInitRank on every rank's own GPU
+        if uid[0] is not None:
+            try:
+                pt.comm_init(uid[0], rank, world)  # collective: ncclCommInitRank on every rank's own GPU
+            except W.WfptError as e:
+                err = str(e)
+        # every rank must take the same path: if the communicator could not be built anywhere, say so LOUDLY in the JSON line
+        # and move the slabs through host memory instead, so that the run still measures the sharded render
+        flags_t = torch.tensor([0 if (err is None and uid[0] is not None) else 1], dtype=torch.int32)
+        dist.all_reduce(flags_t, op=dist.ReduceOp.MAX)
+        if int(flags_t.item()):
+            rehearsal_gather = True
+            gather_path = f"FALLBACK: gloo through host memory, the RCCL communicator failed ({err or 'on another rank'})"
+            print(f"[bench rank {rank}] {gather_path}", file=sys.stderr, flush=True)
+        else:
+            rehearsal_gather = False
+    else:
+        rehearsal_gather = rehearsal
 
     def gather():
         if world == 1:
             return None
-        if rehearsal:  # ranks share a GPU, which RCCL refuses: slabs go through host memory (gloo)
+        if rehearsal_gather:  # ranks share a GPU (which RCCL refuses) or RCCL is unusable: slabs go through host memory (gloo)
             return tiles.gather_slabs(pt.accumulated(), rank, world, args.width, args.height)
         pt.gather_accumulated()  # peers -> rank 0 over xGMI, de-interleaved on rank 0's GPU; asynchronous on the context's stream
         return None
@@ -220,7 +251,7 @@ def main():
         rays_total = rays
     if world == 1:
         frame = pt.accumulated()
-    elif not rehearsal and rank == 0:
+    elif not rehearsal_gather and rank == 0:
         frame = pt.gathered()  # outside the timed region: the frame crosses PCIe only for the dump / the check
 
     # ---- per-stage times and the roofline of the dominant kernel: same K steps again with hipEvent pairs around
@@ -265,7 +296,7 @@ def main():
         return
 
     out = {
-        "metric": f"Mrays/s (extend+shade) at {args.width}x{args.height}, {args.steps} spp, {args.bounces} bounces; 1/2/4/8 GPU",
+        "metric": baseline_metric(),  # BASELINE.json's metric, verbatim; config.workload says what THIS run rendered (K = spp)
         "value": round(float(rays_total[0]) / elapsed / 1e6, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -286,7 +317,7 @@ def main():
                    "launch": "direct" if args.no_graph else "hipGraph",
                    "samples_in_flight": sorted({min(batch, args.steps), args.steps % batch} - {0}, reverse=True),
                    "parallelism": "single GPU" if world == 1 else
-                   f"pixel bands of 8 rows over {world} ranks + 1 gather ({'RCCL send/recv to rank 0 behind the C ABI' if not rehearsal else 'gloo REHEARSAL, ranks share GPUs'})",
+                   f"pixel bands of 8 rows over {world} ranks + 1 gather ({gather_path})",
                    "rays_traced": int(rays_total[0])},
     }
     info = W.device_info(gpu_index)
