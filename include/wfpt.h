@@ -425,6 +425,10 @@ int wfpt_selftest_math(int device, int op, const float *a, const float *b, float
 /* Workgroups of the extend kernel that fit one CU when each declares `lds_bytes` of dynamic LDS (occupancy query;
  * negative status on error). Diagnostic for sizing the LDS-resident scene. */
 int wfpt_debug_extend_blocks_per_cu(int device, uint32_t lds_bytes);
+/* Host-side check of the four-wide quantised tree the device walks for scenes beyond LDS (no GPU needed): collapses
+ * `nodes` and verifies that every quantised child box encloses the binary node's box and that the two trees have the
+ * same leaves. counts = {four-wide nodes, depth, leaf children, inner children}. */
+int wfpt_debug_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, uint32_t counts[4]);
 /* Static facts about the built library, e.g. "gfx950;chunk=512;..." */
 const char *wfpt_build_info(void);
 

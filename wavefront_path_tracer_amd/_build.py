@@ -11,7 +11,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwfpt.so")
 SOURCES = ["wfpt_kernels.hip", "wfpt_api.hip", "wfpt_bvh_build.hip", "wfpt_host.cpp"]
-HEADERS = [os.path.join(CSRC, "wfpt_kernels.h"), os.path.join(CSRC, "wfpt_device_math.h"),
+HEADERS = [os.path.join(CSRC, "wfpt_kernels.h"), os.path.join(CSRC, "wfpt_bvh4.h"), os.path.join(CSRC, "wfpt_device_math.h"),
            os.path.join(ROOT, "include", "wfpt.h")]
 # -ffp-contract=off: results must be bit-identical to the oracle, the only fused ops are explicit fmaf.
 # Correctly rounded fp32 divide/sqrt is hipcc's default and is requested explicitly anyway.

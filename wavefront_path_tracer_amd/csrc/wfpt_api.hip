@@ -177,97 +177,6 @@ int validate_bvh(wfpt_ctx *c, const wfpt_bvh_node *nodes, uint32_t n_nodes, uint
     return static_cast<int>(max_depth);
 }
 
-// Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into four-wide nodes: the children of node N are
-// its grandchildren where a child is an inner node, and the child itself where it is a leaf; the child boxes are
-// quantised to 8 bits per plane in the frame of their union, rounded OUTWARDS under the device's own dequantisation
-// arithmetic (plane = fmaf(q, 2^e, origin)), so a quantised box always encloses the caller's. Returns false when a leaf
-// cannot be written as a child word (more than kLeafMaxCount primitives or an index beyond 28 bits) or a box is not
-// finite: the caller then keeps the binary traversal. `depth4` = levels of four-wide nodes below the root node.
-bool collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vector<Node4> &out, uint32_t &depth4) {
-    out.clear();
-    depth4 = 0;
-    auto leaf_word = [&](const wfpt_bvh_node &nd, uint32_t &w) {
-        if (nd.prim_count > kLeafMaxCount || nd.left_first > kLeafFirstMask) return false;
-        w = kLeafFlag | (nd.prim_count << kLeafCountShift) | nd.left_first;
-        return true;
-    };
-    // quantises the boxes of `kids` (binary node indices) into nd4; false if a bound is not finite
-    auto quantise = [&](Node4 &nd4, const uint32_t *kids, uint32_t n_kids) {
-        std::memset(&nd4, 0, sizeof nd4);
-        for (int ax = 0; ax < 3; ++ax) {
-            float lo = INFINITY, hi = -INFINITY;
-            for (uint32_t k = 0; k < n_kids; ++k) {
-                lo = std::min(lo, nodes[kids[k]].aabb_min[ax]);
-                hi = std::max(hi, nodes[kids[k]].aabb_max[ax]);
-            }
-            if (!std::isfinite(lo) || !std::isfinite(hi) || hi < lo) return false;
-            nd4.origin[ax] = lo;
-            int e = 127;
-            (void)std::frexp((hi - lo) / 255.0f, &e); // (hi - lo) / 255 = m * 2^e, 0.5 <= m < 1  =>  255 * 2^e >= hi - lo
-            int biased = std::min(std::max(e + 127, 1), 254);
-            for (;; ++biased) { // grow the scale until every upper plane fits 8 bits under the device's arithmetic
-                if (biased > 254) return false;
-                float scale;
-                const uint32_t bits = static_cast<uint32_t>(biased) << 23;
-                std::memcpy(&scale, &bits, 4);
-                bool fits = true;
-                for (uint32_t k = 0; k < n_kids && fits; ++k) {
-                    const float cmin = nodes[kids[k]].aabb_min[ax], cmax = nodes[kids[k]].aabb_max[ax];
-                    int ql = static_cast<int>(std::floor((cmin - lo) / scale));
-                    ql = std::min(std::max(ql, 0), 255);
-                    while (ql > 0 && std::fmaf(static_cast<float>(ql), scale, lo) > cmin) --ql; // q = 0 gives lo <= cmin exactly
-                    int qh = static_cast<int>(std::ceil((cmax - lo) / scale));
-                    qh = std::min(std::max(qh, 0), 255);
-                    while (qh < 255 && std::fmaf(static_cast<float>(qh), scale, lo) < cmax) ++qh;
-                    if (std::fmaf(static_cast<float>(qh), scale, lo) < cmax) { fits = false; break; }
-                    nd4.qlo[ax][k] = static_cast<uint8_t>(ql);
-                    nd4.qhi[ax][k] = static_cast<uint8_t>(qh);
-                }
-                if (fits) { nd4.exp[ax] = static_cast<uint8_t>(biased); break; }
-            }
-        }
-        return true;
-    };
-    struct Item { uint32_t bin, slot, depth; }; // binary inner node -> its four-wide node `slot`
-    std::vector<Item> todo;
-    out.emplace_back();
-    if (nodes[0].prim_count > 0) { // a single leaf: a root node with one leaf child (its box is never tested by the reference either)
-        const uint32_t kid = 0;
-        if (!quantise(out[0], &kid, 1)) return false;
-        for (int k = 0; k < 4; ++k) out[0].child[k] = kEmptyChild;
-        return leaf_word(nodes[0], out[0].child[0]);
-    }
-    todo.push_back({0u, 0u, 0u});
-    while (!todo.empty()) {
-        const Item it = todo.back();
-        todo.pop_back();
-        depth4 = std::max(depth4, it.depth);
-        uint32_t kids[4], n_kids = 0;
-        const uint32_t l = nodes[it.bin].left_first;
-        for (uint32_t c = l; c <= l + 1u; ++c) {
-            if (nodes[c].prim_count > 0) kids[n_kids++] = c;
-            else { kids[n_kids++] = nodes[c].left_first; kids[n_kids++] = nodes[c].left_first + 1u; }
-        }
-        Node4 nd4;
-        if (!quantise(nd4, kids, n_kids)) return false;
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (k >= n_kids) { nd4.child[k] = kEmptyChild; continue; }
-            const wfpt_bvh_node &ch = nodes[kids[k]];
-            if (ch.prim_count > 0) {
-                if (!leaf_word(ch, nd4.child[k])) return false;
-            } else {
-                if (out.size() >= kLeafFlag) return false;
-                nd4.child[k] = static_cast<uint32_t>(out.size());
-                todo.push_back({kids[k], static_cast<uint32_t>(out.size()), it.depth + 1u});
-                out.emplace_back();
-            }
-        }
-        out[it.slot] = nd4;
-    }
-    (void)n_nodes;
-    return true;
-}
-
 void destroy_graph(wfpt_ctx *c) {
     for (auto &kv : c->graphs) {
         if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);

@@ -6,7 +6,9 @@
 // association order the Rust/glam source uses, so results are reproducible across compilers.
 // Citations are relative to the reference root (wc = wavefront_common/src).
 #include "wfpt.h"
+#include "wfpt_bvh4.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -249,6 +251,151 @@ const char *const kStageNames[WFPT_STAGE_COUNT] = {"generate_rays",    "extend",
                                                    "compact"};
 
 } // namespace
+
+// Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into four-wide nodes: the children of node N are
+// its grandchildren where a child is an inner node, and the child itself where it is a leaf; the child boxes are
+// quantised to 8 bits per plane in the frame of their union, rounded OUTWARDS under the device's own dequantisation
+// arithmetic (plane = fmaf(q, 2^e, origin)), so a quantised box always encloses the caller's. Returns false when a leaf
+// cannot be written as a child word (more than wfpt::kLeafMaxCount primitives or an index beyond 28 bits) or a box is not
+// finite: the caller then keeps the binary traversal. `depth4` = levels of four-wide nodes below the root node.
+bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vector<wfpt::Node4> &out, uint32_t &depth4) {
+    out.clear();
+    depth4 = 0;
+    auto leaf_word = [&](const wfpt_bvh_node &nd, uint32_t &w) {
+        if (nd.prim_count > wfpt::kLeafMaxCount || nd.left_first > wfpt::kLeafFirstMask) return false;
+        w = wfpt::kLeafFlag | (nd.prim_count << wfpt::kLeafCountShift) | nd.left_first;
+        return true;
+    };
+    // quantises the boxes of `kids` (binary node indices) into nd4; false if a bound is not finite
+    auto quantise = [&](wfpt::Node4 &nd4, const uint32_t *kids, uint32_t n_kids) {
+        std::memset(&nd4, 0, sizeof nd4);
+        for (int ax = 0; ax < 3; ++ax) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (uint32_t k = 0; k < n_kids; ++k) {
+                lo = std::min(lo, nodes[kids[k]].aabb_min[ax]);
+                hi = std::max(hi, nodes[kids[k]].aabb_max[ax]);
+            }
+            if (!std::isfinite(lo) || !std::isfinite(hi) || hi < lo) return false;
+            nd4.origin[ax] = lo;
+            int e = 127;
+            (void)std::frexp((hi - lo) / 255.0f, &e); // (hi - lo) / 255 = m * 2^e, 0.5 <= m < 1  =>  255 * 2^e >= hi - lo
+            int biased = std::min(std::max(e + 127, 1), 254);
+            for (;; ++biased) { // grow the scale until every upper plane fits 8 bits under the device's arithmetic
+                if (biased > 254) return false;
+                float scale;
+                const uint32_t bits = static_cast<uint32_t>(biased) << 23;
+                std::memcpy(&scale, &bits, 4);
+                bool fits = true;
+                for (uint32_t k = 0; k < n_kids && fits; ++k) {
+                    const float cmin = nodes[kids[k]].aabb_min[ax], cmax = nodes[kids[k]].aabb_max[ax];
+                    int ql = static_cast<int>(std::floor((cmin - lo) / scale));
+                    ql = std::min(std::max(ql, 0), 255);
+                    while (ql > 0 && std::fmaf(static_cast<float>(ql), scale, lo) > cmin) --ql; // q = 0 gives lo <= cmin exactly
+                    int qh = static_cast<int>(std::ceil((cmax - lo) / scale));
+                    qh = std::min(std::max(qh, 0), 255);
+                    while (qh < 255 && std::fmaf(static_cast<float>(qh), scale, lo) < cmax) ++qh;
+                    if (std::fmaf(static_cast<float>(qh), scale, lo) < cmax) { fits = false; break; }
+                    nd4.qlo[ax][k] = static_cast<uint8_t>(ql);
+                    nd4.qhi[ax][k] = static_cast<uint8_t>(qh);
+                }
+                if (fits) { nd4.exp[ax] = static_cast<uint8_t>(biased); break; }
+            }
+        }
+        return true;
+    };
+    struct Item { uint32_t bin, slot, depth; }; // binary inner node -> its four-wide node `slot`
+    std::vector<Item> todo;
+    out.emplace_back();
+    if (nodes[0].prim_count > 0) { // a single leaf: a root node with one leaf child (its box is never tested by the reference either)
+        const uint32_t kid = 0;
+        if (!quantise(out[0], &kid, 1)) return false;
+        for (int k = 0; k < 4; ++k) out[0].child[k] = wfpt::kEmptyChild;
+        return leaf_word(nodes[0], out[0].child[0]);
+    }
+    todo.push_back({0u, 0u, 0u});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        depth4 = std::max(depth4, it.depth);
+        uint32_t kids[4], n_kids = 0;
+        const uint32_t l = nodes[it.bin].left_first;
+        for (uint32_t c = l; c <= l + 1u; ++c) {
+            if (nodes[c].prim_count > 0) kids[n_kids++] = c;
+            else { kids[n_kids++] = nodes[c].left_first; kids[n_kids++] = nodes[c].left_first + 1u; }
+        }
+        wfpt::Node4 nd4;
+        if (!quantise(nd4, kids, n_kids)) return false;
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k >= n_kids) { nd4.child[k] = wfpt::kEmptyChild; continue; }
+            const wfpt_bvh_node &ch = nodes[kids[k]];
+            if (ch.prim_count > 0) {
+                if (!leaf_word(ch, nd4.child[k])) return false;
+            } else {
+                if (out.size() >= wfpt::kLeafFlag) return false;
+                nd4.child[k] = static_cast<uint32_t>(out.size());
+                todo.push_back({kids[k], static_cast<uint32_t>(out.size()), it.depth + 1u});
+                out.emplace_back();
+            }
+        }
+        out[it.slot] = nd4;
+    }
+    (void)n_nodes;
+    return true;
+}
+
+
+extern "C" int wfpt_debug_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, uint32_t counts[4]) {
+    // Test hook (no GPU needed): collapses a binary tree into the quantised four-wide nodes the device walks and checks,
+    // with the device's dequantisation arithmetic, that every child box encloses the binary node's box it stands for and
+    // that every leaf / inner node of the binary tree is reachable exactly once. counts = {four-wide nodes, depth,
+    // leaf children, inner children}. Returns WFPT_OK, WFPT_ERR_UNSUPPORTED if the tree cannot be collapsed, or
+    // WFPT_ERR_INVALID_ARGUMENT on a violated property.
+    if (!nodes || n_nodes == 0 || !counts) return WFPT_ERR_INVALID_ARGUMENT;
+    std::vector<wfpt::Node4> n4;
+    uint32_t depth4 = 0;
+    if (!wfpt::collapse_bvh4(nodes, n_nodes, n4, depth4)) return WFPT_ERR_UNSUPPORTED;
+    // walk both trees together: four-wide node `slot` stands for binary inner node `bin`
+    struct Item { uint32_t bin, slot; };
+    std::vector<Item> todo;
+    uint32_t leaves = 0, inners = 0;
+    std::vector<uint8_t> seen(n4.size(), 0);
+    if (nodes[0].prim_count == 0) todo.push_back({0u, 0u});
+    else leaves = 1;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.slot >= n4.size() || seen[it.slot]++) return WFPT_ERR_INVALID_ARGUMENT;
+        const wfpt::Node4 &nd = n4[it.slot];
+        uint32_t kids[4], n_kids = 0;
+        const uint32_t l = nodes[it.bin].left_first;
+        for (uint32_t c = l; c <= l + 1u; ++c) {
+            if (nodes[c].prim_count > 0) kids[n_kids++] = c;
+            else { kids[n_kids++] = nodes[c].left_first; kids[n_kids++] = nodes[c].left_first + 1u; }
+        }
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k >= n_kids) { if (nd.child[k] != wfpt::kEmptyChild) return WFPT_ERR_INVALID_ARGUMENT; continue; }
+            const wfpt_bvh_node &ch = nodes[kids[k]];
+            for (int ax = 0; ax < 3; ++ax) {
+                float scale;
+                const uint32_t bits = static_cast<uint32_t>(nd.exp[ax]) << 23;
+                std::memcpy(&scale, &bits, 4);
+                const float lo = std::fmaf(static_cast<float>(nd.qlo[ax][k]), scale, nd.origin[ax]);
+                const float hi = std::fmaf(static_cast<float>(nd.qhi[ax][k]), scale, nd.origin[ax]);
+                if (!(lo <= ch.aabb_min[ax]) || !(hi >= ch.aabb_max[ax])) return WFPT_ERR_INVALID_ARGUMENT;
+            }
+            if (ch.prim_count > 0) {
+                if (nd.child[k] != (wfpt::kLeafFlag | (ch.prim_count << wfpt::kLeafCountShift) | ch.left_first)) return WFPT_ERR_INVALID_ARGUMENT;
+                ++leaves;
+            } else {
+                if (nd.child[k] & wfpt::kLeafFlag) return WFPT_ERR_INVALID_ARGUMENT;
+                ++inners;
+                todo.push_back({kids[k], nd.child[k]});
+            }
+        }
+    }
+    counts[0] = static_cast<uint32_t>(n4.size()); counts[1] = depth4; counts[2] = leaves; counts[3] = inners;
+    return WFPT_OK;
+}
 
 extern "C" {
 
