@@ -322,6 +322,15 @@ class PathTracer {
         check(wfpt_read_accumulated(ctx_, a.data(), a.size()));
         return a;
     }
+    // Multi-GPU (build-side addition, include/wfpt.h): this context was created with Options::tile_rank / tile_world;
+    // rank 0 makes the 128-byte id with wfpt::comm_unique_id() and hands it to every rank.
+    void comm_init(const std::array<uint8_t, WFPT_COMM_UNIQUE_ID_BYTES> &id, int rank, int world) { check(wfpt_comm_init(ctx_, id.data(), rank, world)); }
+    void gather_accumulated() { check(wfpt_gather_accumulated(ctx_)); } // peers -> rank 0 over xGMI, asynchronous
+    std::vector<float> gathered(uint32_t width, uint32_t height) {     // rank 0: the assembled frame
+        std::vector<float> a(3 * static_cast<size_t>(width) * height);
+        check(wfpt_read_gathered(ctx_, a.data(), a.size()));
+        return a;
+    }
     uint32_t last_wavefronts() const { return last_wavefronts_; }
     wfpt_ctx *handle() { return ctx_; }
     Kernel &generate_ray_kernel() { return generate_ray_kernel_; }
@@ -342,5 +351,12 @@ class PathTracer {
     Kernel generate_ray_kernel_, extend_kernel_, shade_kernel_, miss_kernel_, accumulate_kernel_;
     uint32_t last_wavefronts_ = 0;
 };
+
+inline std::array<uint8_t, WFPT_COMM_UNIQUE_ID_BYTES> comm_unique_id() {
+    std::array<uint8_t, WFPT_COMM_UNIQUE_ID_BYTES> id{};
+    const int st = wfpt_comm_unique_id(id.data());
+    if (st != WFPT_OK) throw Error(st, wfpt_last_error(nullptr));
+    return id;
+}
 
 } // namespace wfpt
