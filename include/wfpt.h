@@ -201,8 +201,9 @@ typedef struct wfpt_params {
     uint32_t tile_rank;      /* pixel-tile sharding: this context owns the 8-pixel-high bands k with */
     uint32_t tile_world;     /*   k % tile_world == tile_rank; 0 or 1 = whole image */
     int32_t device;          /* HIP device ordinal */
-    uint32_t batch;          /* samples kept in flight per launch by wfpt_render (1..64; 0 = 16). Results are
-                                bit-identical for every value: samples are independent and accumulate in order. */
+    uint32_t batch;          /* samples kept in flight per launch by wfpt_render (1..128, 1..64 for the stage-by-stage
+                                loop; 0 = 16; larger values are clamped). Results are bit-identical for every value:
+                                samples are independent and accumulate in order. */
 } wfpt_params;
 
 typedef struct wfpt_ctx wfpt_ctx;

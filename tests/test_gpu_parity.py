@@ -302,6 +302,23 @@ def test_error_paths(gpu):
     pt.close()
 
 
+def test_many_samples_in_flight(gpu, orc):
+    """More samples in flight than the stage-by-stage loop supports (the fused launches take up to 128; a request beyond
+    that is clamped, the unfused loop clamps at 64): same image as the oracle's sequential samples, remainder included."""
+    W = gpu
+    w, h, bounces = 96, 64, 5
+    spp = 128 + 37
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
+    want = o.render(spp)
+    for batch, flags in ((128, 0), (100, W.FLAG_NO_GRAPH), (500, 0), (128, W.FLAG_UNFUSED)):
+        pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
+        pt.render(spp)
+        assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")
+        assert np.array_equal(pt.totals(), o.totals())
+        pt.close()
+    o.close()
+
+
 @pytest.mark.parametrize("batch", [1, 4, 8, 16])
 def test_batched_samples_equal_sequential(gpu, orc, batch):
     """wfpt_render keeps `batch` samples in flight per launch; samples are independent and accumulate in frame

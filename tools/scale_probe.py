@@ -13,6 +13,6 @@ def run(world, batch):
 base = run(1, 32)
 print(f"N=1 batch 32: {base:.4f} ms/sample")
 for world in (2, 4, 8):
-    for batch in (32, 64):
+    for batch in (32, 64, 128):
         ms = run(world, batch)
         print(f"N={world} batch {batch}: {ms:.4f} ms/sample of the slab -> speed-up {base / ms:.2f}x, efficiency {base / ms / world:.2f}", flush=True)

@@ -665,8 +665,9 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     if (cap == 0) cap = kChunk;
     c->capacity = static_cast<uint32_t>(cap);
     c->n_chunks_max = c->capacity / kChunk;
-    c->batch_max = params->batch == 0 ? 16u : std::min<uint32_t>(params->batch, kMaxBatch);
-    c->fused = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE)) == 0;
+    // the fused bounce launches keep their per-sample work-item counts as u16 in LDS: larger images stay on the stage kernels
+    c->fused = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE)) == 0 && c->n_chunks_max <= 65535u;
+    c->batch_max = params->batch == 0 ? 16u : std::min<uint32_t>(params->batch, c->fused ? kMaxBatch : kMaxBatchClassic);
     c->classic_batch = c->fused ? 1u : c->batch_max; // the stage API works on slice 0 only
     const size_t nb_all = c->batch_max;
     const size_t nb = c->classic_batch;

@@ -27,7 +27,8 @@ constexpr int kConsumerThreads = WFPT_CONSUMER_THREADS;
 constexpr int kScanThreads = 1024;
 constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
 constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64
-constexpr int kMaxBatch = 64;      // samples kept in flight by one launch of the device-resident loop
+constexpr int kMaxBatch = 128;     // samples kept in flight by one launch of the device-resident loop (fused bounce launches)
+constexpr int kMaxBatchClassic = 64; // ... by the stage kernels one by one (WFPT_FLAG_UNFUSED / WFPT_FLAG_SPLIT_SHADE): their LDS tables are per sample
 
 // SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed. The seven planes of a
 // slice sit `cap` elements apart behind one base pointer (3 SGPRs per queue in a kernel instead of 14).

@@ -513,12 +513,12 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
     const uint32_t geom_words = LDS_SCENE ? kGeomWords * a.scene.n_spheres : 0u;
     uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_sphere + geom_words);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_sphere + geom_words + parent_words);
-    // s_misc: [2][2][kExtendWaves] wave counts, [2] next work item, [kMaxBatch] rays per sample,
-    //         [kMaxBatch + 1] first work item of each sample
+    // s_misc: [2][2][kExtendWaves] wave counts, [2] next work item, [kMaxBatchClassic] rays per sample,
+    //         [kMaxBatchClassic + 1] first work item of each sample
     uint32_t *s_next = s_misc + 4 * kExtendWaves;
     uint32_t *s_rays = s_next + 2;
-    uint32_t *s_first = s_rays + kMaxBatch;
-    uint32_t *s_mat = s_first + kMaxBatch + 1; // [2][3][kExtendWaves] per-material wave counts
+    uint32_t *s_first = s_rays + kMaxBatchClassic;
+    uint32_t *s_mat = s_first + kMaxBatchClassic + 1; // [2][3][kExtendWaves] per-material wave counts
     uint32_t *s_stack = s_mat + 6 * kExtendWaves; // HBM-resident scenes: [2 * kStackDepth][kExtendThreads] node stack (node, packed fields)
 
     // Work items are (sample, segment) pairs, numbered sample-major.
@@ -1039,12 +1039,13 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
 struct BounceLds {
     uint32_t *cnt;     // [2][2][kExtendWaves] per-wave hit / miss counts, double-buffered by iteration parity
     uint32_t *next;    // [2] next work item
-    uint32_t *n_hit;   // [kMaxBatch] hits to shade (first wavefront: ray slots) per sample
-    uint32_t *first_h; // [kMaxBatch + 1] first hit item of each sample
-    uint32_t *first_m; // [kMaxBatch + 1] first miss item of each sample
+    uint32_t *total;   // [2] hit items, all items of this launch
+    uint16_t *items_h; // [kMaxBatch] hit work items of each sample (u16: the four LDS-resident scene copies of a CU leave ~1 KB)
+    uint16_t *items_m; // [kMaxBatch] miss work items of each sample
     uint32_t *stack;   // HBM-resident scenes: [2 * kStackDepth][kExtendThreads]
 };
-constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + kMaxBatch + 2u * (kMaxBatch + 1u) + 4u; // +4: keeps `stack` 16-byte aligned
+constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + 2u + kMaxBatch; // the two u16 tables take kMaxBatch words
+static_assert(kBounceMiscWords % 4u == 0, "the stack column area stays 16-byte aligned");
 
 template <int MODE, typename Trail, int PRIM, bool LDS_SCENE>
 __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_kernel(BounceArgs a) {
@@ -1061,31 +1062,34 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     BounceLds L;
     L.cnt = s_misc;
     L.next = L.cnt + 4 * kExtendWaves;
-    L.n_hit = L.next + 2;
-    L.first_h = L.n_hit + kMaxBatch;
-    L.first_m = L.first_h + kMaxBatch + 1;
+    L.total = L.next + 2;
+    L.items_h = reinterpret_cast<uint16_t *>(L.total + 2);
+    L.items_m = L.items_h + kMaxBatch;
     L.stack = s_misc + kBounceMiscWords;
 
     const uint32_t n_slots = a.gx * a.gy * 64u; // first wavefront: ray slots of this context's tiles
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) { // (a context has at most 65535 segments: wfpt_create keeps larger images on the stage-by-stage loop)
         uint32_t total = 0;
         for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
             const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
-            L.n_hit[smp] = n;
-            L.first_h[smp] = total;
-            total += (n + kChunk - 1) / kChunk;
+            const uint32_t items = (n + kChunk - 1) / kChunk;
+            L.items_h[smp] = static_cast<uint16_t>(items);
+            total += items;
         }
-        L.first_h[a.batch.n] = total;
+        L.total[0] = total;
         for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
             uint32_t segs = 0;
             if (MODE != kBounceFirst && a.ctl[smp].miss_n > 0) segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
-            L.first_m[smp] = total;
-            total += (segs + kMissSegsPerItem - 1) / kMissSegsPerItem;
+            const uint32_t items = (segs + kMissSegsPerItem - 1) / kMissSegsPerItem;
+            L.items_m[smp] = static_cast<uint16_t>(items);
+            total += items;
         }
-        L.first_m[a.batch.n] = total;
+        L.total[1] = total;
     }
     __syncthreads();
-    const uint32_t n_hit_items = L.first_h[a.batch.n], n_items = L.first_m[a.batch.n];
+    const uint32_t n_hit_items = L.total[0], n_items = L.total[1];
+    // a workgroup's tickets only grow, so the sample of an item is found by walking on from where the previous item was
+    uint32_t smp_h = 0, first_h = 0, smp_m = 0, first_m = n_hit_items;
     if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n)
         a.ctl[threadIdx.x].n_in = umin(n_slots, a.capacity); // pt:313-316: counter[2] = rays of the first wavefront (read by scan)
     uint32_t item = blockIdx.x;
@@ -1107,9 +1111,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         if (item >= n_hit_items) {
             // ---------------- miss_kernel (mk:13-38) for kMissSegsPerItem segments of the previous wavefront's miss queue
-            uint32_t smp = 0;
-            while (item >= L.first_m[smp + 1]) ++smp;
-            const uint32_t first_seg = (item - L.first_m[smp]) * kMissSegsPerItem;
+            while (item >= first_m + L.items_m[smp_m]) first_m += L.items_m[smp_m++];
+            const uint32_t smp = smp_m;
+            const uint32_t first_seg = (item - first_m) * kMissSegsPerItem;
             const uint32_t n_segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
             const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
             float *image = a.image + smp * a.batch.image_stride;
@@ -1138,10 +1142,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             iter += 1;
             continue;
         }
-        uint32_t smp = 0;
-        while (item >= L.first_h[smp + 1]) ++smp; // block-uniform
-        const uint32_t seg_out = item - L.first_h[smp];
-        const uint32_t n = L.n_hit[smp];
+        while (item >= first_h + L.items_h[smp_h]) first_h += L.items_h[smp_h++]; // block-uniform
+        const uint32_t smp = smp_h;
+        const uint32_t seg_out = item - first_h;
+        const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
         const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
         float *image = a.image + smp * a.batch.image_stride;
         wfpt_frame_buffer fb = fb0;
@@ -1534,7 +1538,7 @@ __global__ void selftest_math_kernel(int op, const float *a, const float *b, flo
 // launchers
 // ================================================================================================
 uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene) {
-    const uint32_t misc = 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatch + 1u + 6u * kExtendWaves) + 16u;
+    const uint32_t misc = 4u * (4u * kExtendWaves + 2u + 2u * kMaxBatchClassic + 1u + 6u * kExtendWaves) + 16u;
     if (!lds_scene) return misc + 4u * 2u * kStackDepth * kExtendThreads; // a stack entry is (node, packed fields)
     const uint32_t parent_words = ((n_nodes / 2u + 1u) + 7u) / 8u;
     return 32u * n_nodes + 16u * (prim_kind == 0 ? 1u : 3u) * n_prims + 16u * parent_words + misc;
