@@ -521,14 +521,15 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
     uint32_t *s_mat = s_first + kMaxBatchClassic + 1; // [2][3][kExtendWaves] per-material wave counts
     uint32_t *s_stack = s_mat + 6 * kExtendWaves; // HBM-resident scenes: [2 * kStackDepth][kExtendThreads] node stack (node, packed fields)
 
-    // Work items are (sample, segment) pairs, numbered sample-major.
+    // Work items are (sample, segment) pairs, numbered sample-major. The samples' counters are read side by side (one
+    // thread each); the prefix over them then runs out of LDS.
+    if (threadIdx.x < a.batch.n) s_rays[threadIdx.x] = umin(a.n_in[static_cast<size_t>(threadIdx.x) * a.batch.ctl_stride], a.limit);
+    __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-            const uint32_t n = umin(a.n_in[static_cast<size_t>(smp) * a.batch.ctl_stride], a.limit);
-            s_rays[smp] = n;
             s_first[smp] = total;
-            total += (n + kChunk - 1) / kChunk;
+            total += (s_rays[smp] + kChunk - 1) / kChunk;
         }
         s_first[a.batch.n] = total;
     }
@@ -1068,23 +1069,22 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     L.stack = s_misc + kBounceMiscWords;
 
     const uint32_t n_slots = a.gx * a.gy * 64u; // first wavefront: ray slots of this context's tiles
-    if (threadIdx.x == 0) { // (a context has at most 65535 segments: wfpt_create keeps larger images on the stage-by-stage loop)
-        uint32_t total = 0;
-        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-            const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
-            const uint32_t items = (n + kChunk - 1) / kChunk;
-            L.items_h[smp] = static_cast<uint16_t>(items);
-            total += items;
-        }
-        L.total[0] = total;
-        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-            uint32_t segs = 0;
-            if (MODE != kBounceFirst && a.ctl[smp].miss_n > 0) segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
-            const uint32_t items = (segs + kMissSegsPerItem - 1) / kMissSegsPerItem;
-            L.items_m[smp] = static_cast<uint16_t>(items);
-            total += items;
-        }
-        L.total[1] = total;
+    // Work-item tables, one thread per sample: the counters of the samples are read side by side (a loop in one thread paid one
+    // global-memory round trip per sample and launch: ~45 us at 32 samples in flight, on launches of 0.1-1 ms).
+    // (a context has at most 65535 segments: wfpt_create keeps larger images on the stage-by-stage loop)
+    if (threadIdx.x < 2) L.total[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < a.batch.n) {
+        const uint32_t smp = threadIdx.x;
+        const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
+        const uint32_t items_h = (n + kChunk - 1) / kChunk;
+        uint32_t segs = 0;
+        if (MODE != kBounceFirst && a.ctl[smp].miss_n > 0) segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
+        const uint32_t items_m = (segs + kMissSegsPerItem - 1) / kMissSegsPerItem;
+        L.items_h[smp] = static_cast<uint16_t>(items_h);
+        L.items_m[smp] = static_cast<uint16_t>(items_m);
+        atomicAdd(&L.total[0], items_h);           // hit items
+        atomicAdd(&L.total[1], items_h + items_m); // all items of this launch
     }
     __syncthreads();
     const uint32_t n_hit_items = L.total[0], n_items = L.total[1];
@@ -1249,13 +1249,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     uint32_t *s_first = s_n + kMaxBatch;                  // [kMaxBatch + 1] first global ray index of each sample
     uint32_t *s_stack = s_first + kMaxBatch + 4;          // [kStack4Lds][kExtendThreads]
     const uint32_t n_slots = a.gx * a.gy * 64u;
+    if (threadIdx.x < a.batch.n) // the samples' counters, read side by side
+        s_n[threadIdx.x] = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[threadIdx.x].shade_n, a.capacity);
+    __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-            const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
-            s_n[smp] = n;
             s_first[smp] = total;
-            total += n;
+            total += s_n[smp];
         }
         s_first[a.batch.n] = total;
     }
