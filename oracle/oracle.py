@@ -96,6 +96,8 @@ def lib(serial=False):
     L.orc_traversal_profile.argtypes = [vp, u32, vp]
     L.orc_ray_rounds.argtypes = [vp, u32, vp, vp]
     L.orc_sim_postpone.argtypes = [vp, u32, u32, vp]
+    L.orc_prim_hit_t.argtypes = [vp, u32, u32, vp]
+    L.orc_ray_rounds_init.argtypes = [vp, u32, vp, C.c_int, vp, vp]
     L.orc_write_rays.argtypes = [vp, vp, u32]
     L.orc_camera_new.argtypes = [vp, vp, C.POINTER(f32), C.POINTER(f32)]
     L.orc_view_transform.argtypes = [vp, f32, f32, vp]

@@ -922,6 +922,63 @@ void orc_ray_rounds(orc_ctx *c, uint32_t n, uint8_t *segs, uint8_t *n_leaves) {
     }
 }
 
+/* Diagnostics for kernel design: t of primitive `prim` for each ray of the current queue (1e30 = not hit), and
+ * orc_ray_rounds for a traversal that starts with `nearest` already set per ray (a primitive tested ahead of the tree) and
+ * optionally tests the root's own box first (the reference never does, ex:84). */
+void orc_prim_hit_t(orc_ctx *c, uint32_t n, uint32_t prim, float *t_out) {
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t idx = 0; idx < (int64_t)n; idx++) {
+        const orc_ray *ray = &c->rays[idx];
+        orc_hit_payload nh;
+        t_out[idx] = 1e30f;
+        if (ray->pixel_idx == ORC_INACTIVE_PIXEL) continue;
+        if (hit_prim(c, ray, prim, 0.001f, 1e30f, &nh)) t_out[idx] = nh.t;
+    }
+}
+void orc_ray_rounds_init(orc_ctx *c, uint32_t n, const float *init_nearest, int test_root, uint8_t *segs, uint8_t *n_leaves) {
+    const int no_blind_descent = test_root & 2; /* bit 1: a pair missed by the ray is never entered (the reference enters it while nothing is hit yet, ex:126) */
+    test_root &= 1;
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t idx = 0; idx < (int64_t)n; idx++) {
+        const orc_ray *ray = &c->rays[idx];
+        uint8_t *sg = segs + 16 * idx;
+        memset(sg, 0, 16);
+        n_leaves[idx] = 0;
+        if (ray->pixel_idx == ORC_INACTIVE_PIXEL) continue;
+        float nearest_hit = init_nearest[idx];
+        orc_bvh_node stack[ORC_MAX_STACK];
+        uint32_t sp = 0, k = 0;
+        orc_bvh_node node = c->nodes[0];
+        if (test_root && hit_bvh_node(&node, ray, nearest_hit) >= 1e30f) continue;
+        for (;;) {
+            int pop = 0;
+            if (node.prim_count > 0) {
+                for (uint32_t i = 0; i < node.prim_count; i++) {
+                    orc_hit_payload nh;
+                    if (hit_prim(c, ray, node.left_first + i, 0.001f, nearest_hit, &nh)) nearest_hit = nh.t;
+                }
+                if (n_leaves[idx] < 255) n_leaves[idx]++;
+                if (k < 15) k++;
+                pop = 1;
+            } else {
+                if (sg[k] < 255) sg[k]++;
+                orc_bvh_node left = c->nodes[node.left_first], right = c->nodes[node.left_first + 1];
+                float t_left = hit_bvh_node(&left, ray, nearest_hit), t_right = hit_bvh_node(&right, ray, nearest_hit);
+                if (t_left > t_right) {
+                    float tt = t_left; t_left = t_right; t_right = tt;
+                    orc_bvh_node tn = left; left = right; right = tn;
+                }
+                if (t_left > nearest_hit || (no_blind_descent && t_left >= 1e30f)) pop = 1;
+                else { node = left; if (t_right < nearest_hit) stack[sp++] = right; }
+            }
+            if (pop) {
+                if (sp == 0) break;
+                node = stack[--sp];
+            }
+        }
+    }
+}
+
 /* Diagnostics for kernel design: cost model of a wave64 "while-while" schedule with up to Q postponed leaves per lane
  * (Q = 0: a lane that reaches a leaf waits for the leaf phase, the schedule extend_kernel uses). A lane with a free
  * slot notes the leaf, pops and keeps traversing with its `nearest` not yet updated (speculative: visits more nodes,

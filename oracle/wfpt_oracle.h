@@ -141,6 +141,8 @@ int      orc_trace_bvh(orc_ctx *, const orc_ray *ray, orc_hit_payload *out);
 /* diagnostics: inner-node and leaf steps of each of the first n rays of the current ray queue */
 void     orc_ray_steps(orc_ctx *, uint32_t n, uint16_t *inner_steps, uint16_t *leaf_steps);
 void     orc_ray_rounds(orc_ctx *, uint32_t n, uint8_t *segs, uint8_t *n_leaves); /* diagnostics: inner visits per while-while round */
+void     orc_prim_hit_t(orc_ctx *, uint32_t n, uint32_t prim, float *t_out); /* diagnostics: t of one primitive per ray */
+void     orc_ray_rounds_init(orc_ctx *, uint32_t n, const float *init_nearest, int test_root, uint8_t *segs, uint8_t *n_leaves); /* diagnostics */
 void     orc_sim_postpone(orc_ctx *, uint32_t n, uint32_t Q, uint64_t out[8]); /* diagnostics: wave64 schedule model with postponed leaves */
 void     orc_traversal_profile(orc_ctx *, uint32_t n, uint64_t out[16]); /* diagnostics: push / pop / climb counts of the reference traversal */
 /* display_shader.wgsl:50-52: sqrt(acc / n) -> 8-bit RGB */

@@ -57,7 +57,7 @@ def main():
     line = json.load(open(base + "stats.json"))
     json.dump(line, open(os.path.join(here, f"{rnd}_bench_line_{scene}_{variant}.json"), "w"), indent=1)
     out = {}
-    for d in ("fetch", "write", "sq", "sq2", "tcc", "tcp"):
+    for d in ("fetch", "write", "sq", "sq2", "tcc", "tcp", "ta", "ta2"):
         for p in glob.glob(base + d + "/*/*_counter_collection.csv"):
             for k, counters in pmc(p).items():
                 for c, v in counters.items():
@@ -114,6 +114,12 @@ def main():
         if "SQ_WAIT_ANY" in k and "SQ_WAVE_CYCLES" in k:
             summary["secondary"]["wait_any_frac"] = round(k["SQ_WAIT_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)
             summary["secondary"]["wait_inst_any_frac"] = round(k["SQ_WAIT_INST_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)
+    if "TA_BUSY_avr" in k and "GRBM_GUI_ACTIVE" in k:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, TA_BUSY_avr / _max are per-TA figures: the L1 address path of config 5
+        cyc = k["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        summary["ta_busy_frac"] = {"avr": round(k["TA_BUSY_avr"]["mean"] / cyc, 3), "max": round(k["TA_BUSY_max"]["mean"] / cyc, 3)}
+        if "TA_ADDR_STALLED_BY_TC_CYCLES_sum" in k:
+            summary["ta_busy_frac"]["addr_stalled_by_tc"] = round(k["TA_ADDR_STALLED_BY_TC_CYCLES_sum"]["mean"] / 256.0 / cyc, 3)
     if "TCC_HIT_sum" in k:
         summary["l2_hit_rate"] = k["TCC_HIT_sum"]["mean"] / max(k["TCC_HIT_sum"]["mean"] + k["TCC_MISS_sum"]["mean"], 1.0)
         summary["l2_read_requests_per_launch"] = k.get("TCP_TCC_READ_REQ_sum", {}).get("mean")

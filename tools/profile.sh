@@ -10,7 +10,7 @@ args="--steps 64 --warmup 32 --no-cpu-baseline $*"
 run() { # name, rocprof options...
   name=$1; shift
   rm -rf $out/prof_${tag}_$name
-  timeout -k 10 400 rocprofv3 "$@" --output-format csv -d $out/prof_${tag}_$name -- python3 bench.py $args > $out/prof_${tag}_$name.json 2> $out/prof_${tag}_$name.err \
+  timeout -k 10 240 rocprofv3 "$@" --output-format csv -d $out/prof_${tag}_$name -- python3 bench.py $args > $out/prof_${tag}_$name.json 2> $out/prof_${tag}_$name.err \
     || { echo "pass $name FAILED"; tail -5 $out/prof_${tag}_$name.err; return 1; }
   echo "pass $name ok: $(python3 -c "import json,sys; d=json.load(open('$out/prof_${tag}_$name.json')); print(d['value'], d['roofline']['avg_launch_us'])")"
 }

@@ -146,7 +146,14 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
 // ================================================================================================
 // extend (ex:47-210)
 // ================================================================================================
-// ex:164-183 with the node held as two float4 (min.xyz|left_first, max.xyz|prim_count)
+// ex:164-183 with the node held as two float4 (min.xyz|left_first, max.xyz|prim_count).
+// A missed box reports kBoxMiss, a value ABOVE the reference's 1e30 (ex:181), which is also its "nothing hit yet" value of
+// `nearest`: while nothing is hit the reference's test `t_near > nearest` (ex:124) reads 1e30 > 1e30 = false for a pair
+// of boxes the ray misses both of, and it walks down into that pair, left child first, down to a leaf whose primitive
+// it then tests in vain (the primitive lies inside a box the ray misses). Those visits decide nothing; with the larger
+// miss value the same comparison leaves such a pair alone: 11 % fewer visits for primary rays, 7 % for the others
+// (oracle model, tools/model_schedule.py), the hits unchanged.
+constexpr float kBoxMiss = 3.0e38f;
 __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox, float oy, float oz, float ix,
                                               float iy, float iz, float nearest) {
     const float t_x_min = (bmin.x - ox) * ix;
@@ -161,7 +168,7 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
     const float t_z_max = (bmax.z - oz) * iz;
     tmin = max_(min_(t_z_min, t_z_max), tmin);
     tmax = min_(max_(t_z_min, t_z_max), tmax);
-    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
+    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? kBoxMiss : tmin;
 }
 
 // The same test with each plane distance as ONE fused multiply-add, b * inv + (-(o * inv)): half the arithmetic of
@@ -187,7 +194,7 @@ __device__ __forceinline__ float hit_bvh_node_fma(float4 bmin, float4 bmax, floa
     const float t_z_max = fma_(bmax.z, iz, noz);
     tmin = max_(min_(t_z_min, t_z_max), tmin);
     tmax = min_(max_(t_z_min, t_z_max), tmax);
-    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 1e30f : tmin;
+    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? kBoxMiss : tmin;
 }
 
 #ifndef WFPT_SLAB_FMA
