@@ -11,6 +11,8 @@ import inspect
 import json
 import os
 import re
+
+import numpy as np
 import struct
 import subprocess
 import sys
@@ -111,7 +113,12 @@ def test_kernel_literals(ref):
     assert re.search(r"t > 0\.001f && t < nearest", function_body(dev, "hit_prim"))
     assert "0.33333f" in function_body(dev, "rng_next_in_unit_sphere")
     assert re.search(r"kPi = 3\.1415927f", dev) and re.search(r"ORC_PI 3\.1415927f", orc)
-    assert re.search(r"\? 1e30f : tmin", function_body(dev, "hit_bvh_node"))
+    # the oracle keeps the reference's box-miss value (extend.wgsl:181); the device deliberately reports a LARGER one, so that a
+    # pair of missed boxes is not walked down while `nearest` still holds the no-hit sentinel of the same value
+    assert re.search(r"return 1e30f;", function_body(orc, "hit_bvh_node"))
+    assert re.search(r"\? kBoxMiss : tmin", function_body(dev, "hit_bvh_node"))
+    m = re.search(r"constexpr float kBoxMiss = ([0-9.e+]+)f;", dev)
+    assert m and float(m.group(1)) > ex["box_miss"]["value"] and np.isfinite(np.float32(m.group(1)))
 
 
 def test_builder_and_loop_constants(ref):
