@@ -809,8 +809,11 @@ __device__ __forceinline__ float3_ scatter(uint32_t rng, float3_ p, float3_ rdir
     // spheres: always-outward normal (sh:93); triangles: normalize(cross(e1, e2)), never flipped
     const float3_ nrm = prim_kind == 0 ? normalize3({p.x - rec0.x, p.y - rec0.y, p.z - rec0.z}) : float3_{rec0.x, rec0.y, rec0.z};
     float3_ ext;
+    // metal and lambertian both start with normalize(rng_next_in_unit_sphere) (sh:104, 111): drawn once for the lanes of either
+    // kind, so a wave that holds both materials runs the sampler (pow, sqrt, sin / cos, three divisions) once, not twice
+    float3_ rb = {0.0f, 0.0f, 0.0f};
+    if (mat_type != 2u) rb = normalize3(rng_next_in_unit_sphere(rng));
     if (mat_type == 1u) { // sh:110-114 metal
-        const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
         const float3_ rf = reflect(rdir, nrm);
         ext = {rf.x + fuzz * rb.x, rf.y + fuzz * rb.y, rf.z + fuzz * rb.z};
     } else if (mat_type == 2u) { // sh:115-151 dielectric
@@ -840,7 +843,6 @@ __device__ __forceinline__ float3_ scatter(uint32_t rng, float3_ p, float3_ rdir
             ext = reflect(uv, norm);
         }
     } else { // sh:102-109 lambertian (case 0u, default)
-        const float3_ rb = normalize3(rng_next_in_unit_sphere(rng));
         ext = {nrm.x + rb.x, nrm.y + rb.y, nrm.z + rb.z};
         if (sqrt_(dot3(ext, ext)) < 0.001f) ext = nrm;
     }
