@@ -169,9 +169,10 @@ def main():
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
              (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0) |
              (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0))
-    # samples in flight per launch: 32 at N=1 (16 / 32 / 64: 16.7 / 17.7 / 17.8 Grays/s); each rank of N holds 1/N of the pixels,
-    # so it scales with N (up to the library's 128) to keep launches as large
-    batch = args.batch or min(128, 32 * world)
+    # samples in flight per launch: 64 at N=1 (32 / 64 / 128: 18.8 / 19.4 / 19.6 Grays/s on a 128-spp job: the late wavefronts are
+    # small, and a launch of few work items per workgroup ends on a long tail); each rank of N holds 1/N of the pixels, so it
+    # scales with N (up to the library's 128) to keep launches as large
+    batch = args.batch or min(128, 64 * world)
     kw = dict(seed=args.seed, max_wavefronts=args.bounces, rng_mode=rng_mode, flags=flags, tile_rank=rank,
               tile_world=world, device=gpu_index, batch=batch)
     if args.scene == "mesh":
