@@ -6,7 +6,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 out=gpurun_out
-args="--steps 64 --warmup 32 --no-cpu-baseline $*"
+args="--steps 64 --warmup 64 --no-cpu-baseline $*"
 run() { # name, rocprof options...
   name=$1; shift
   rm -rf $out/prof_${tag}_$name
