@@ -26,6 +26,22 @@ __global__ __launch_bounds__(512) void chase_direct(const float4 *table, const u
     out[tid] = acc;
 }
 
+// the same chase with a record of N x 16 bytes per lane (N = 3: a 48-byte node), records still 64 bytes apart
+template <int N> __global__ __launch_bounds__(512) void chase_n(const float4 *table, const uint32_t *idx, uint32_t n_rec, uint32_t iters, float *out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rec = idx[tid] % n_rec;
+    float acc = 0.0f;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const float4 *p = table + 4u * static_cast<size_t>(rec);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) { const float4 v = p[k]; s += (v.x + v.y) + (v.z + v.w); }
+        acc += s;
+        rec = next_rec(rec, s, n_rec);
+    }
+    out[tid] = acc;
+}
+
 __global__ __launch_bounds__(512) void chase_coop(const float4 *table, const uint32_t *idx, uint32_t n_rec, uint32_t iters, float *out) {
     __shared__ float4 stage[8][256]; // per wave: 64 records x 4 quarters
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,6 +83,19 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (size_t bytes : {size_t(16) << 10, size_t(2) << 20, size_t(64) << 20}) {
         const uint32_t n_rec = static_cast<uint32_t>(bytes / 64u);
+        for (int nload = 1; nload <= 3; ++nload) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                if (nload == 1) hipLaunchKernelGGL(chase_n<1>, dim3(blocks), dim3(threads), 0, 0, t, idx, n_rec, iters, out);
+                if (nload == 2) hipLaunchKernelGGL(chase_n<2>, dim3(blocks), dim3(threads), 0, 0, t, idx, n_rec, iters, out);
+                if (nload == 3) hipLaunchKernelGGL(chase_n<3>, dim3(blocks), dim3(threads), 0, 0, t, idx, n_rec, iters, out);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+            }
+            const double steps = double(blocks) * threads * iters;
+            printf("table %6zu KB  %d x 16 B: %8.3f ms  %6.1f G records/s\n", bytes >> 10, nload, best, steps / best / 1e6);
+        }
         for (int coop = 0; coop < 2; ++coop) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
