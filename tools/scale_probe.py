@@ -10,8 +10,8 @@ def run(world, batch):
     t0 = time.perf_counter(); pt.render(spp); pt.synchronize(); el = time.perf_counter() - t0
     pt.close()
     return el / spp * 1e3
-base = run(1, 32)
-print(f"N=1 batch 32: {base:.4f} ms/sample")
+base = run(1, 64)  # what bench.py runs at N = 1
+print(f"N=1 batch 64: {base:.4f} ms/sample (batch 32: {run(1, 32):.4f})")
 for world in (2, 4, 8):
     for batch in (32, 64, 128):
         ms = run(world, batch)
