@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the wavefront kernel chain on MI355X.
 
-Workload (BASELINE.json configs[1]): seeded Shirley random-spheres scene, 1920x1080, 8 bounces; one STEP is
-one sample per pixel of the whole frame: generate_rays -> 8 x (extend, scan, shade, miss_kernel) -> accumulate.
-Default K = 64 steps = the 64 spp the metric is quoted on. Inputs (scene, BVH, camera) are resident in HBM
-before the timed region; the timed region holds K steps (and, for N > 1, the final RCCL gather).
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): seeded Shirley random-spheres scene,
+1920x1080, 64 samples per pixel, 8 bounces. One STEP is one whole FRAME of that configuration:
 
-  python bench.py --gpus 1 --steps 64 --warmup 4
+    reset accumulation -> 64 samples per pixel (frames 1..64 of the reference's RenderProgress), each sample
+    generate_rays -> 8 x (extend, scan, shade, miss_kernel) -> accumulate, all 64 in flight in one pass of the
+    device-resident loop (path_tracer.rs:291-295 is the reference's spp loop) -> [N > 1: one gather of the frame]
+
+so `--steps K` times K such frames whatever K is (the samples per frame are `--spp`, default 64, never K).
+Inputs (scene, BVH, camera) are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N ...            # no launcher needed: starts its N ranks itself (torch.distributed.run, as a child)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; the frame is sharded by 8-row pixel bands (band k -> rank k % N), no collective
-inside the bounce loop, one gather of the accumulated slabs to rank 0 at the end (scaling = "strong": the
-frame is fixed, per-GPU work shrinks). Rank 0 prints ONE JSON line.
+N > 1: one process per GPU; the frame is sharded by 8-row pixel bands (band k -> rank k % N), no collective inside the
+bounce loop, one RCCL gather of the accumulated slabs to rank 0 per frame (scaling = "strong": the frame is fixed,
+per-GPU work shrinks). Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,8 +49,9 @@ B_GENERATE_PIXEL = 28.0 + 12.0                               # generate_rays: ra
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10, help="timed frames (one step = one frame of --spp samples per pixel)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed frames before the timed ones")
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel of one frame (the metric's configuration: 64)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
@@ -58,22 +67,40 @@ def parse():
     ap.add_argument("--no-refill", action="store_true", help="mesh scene: fused bounce kernel (lanes keep their ray) instead of dynamic lane refill")
     ap.add_argument("--binary-bvh", action="store_true", help="mesh scene: walk the binary tree instead of the four-wide collapse")
     ap.add_argument("--unfused", action="store_true", help="run the stage kernels one by one (extend, scan, shade, miss_kernel per wavefront)")
-    ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = library default, 16)")
+    ap.add_argument("--exact-traversal", action="store_true",
+                    help="WFPT_FLAG_EXACT_TRAVERSAL: the reference's slab arithmetic and 1e30 box-miss value, operation for operation")
+    ap.add_argument("--batch", type=int, default=0, help="samples kept in flight per launch (0 = all --spp samples of a frame, at most 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0,
-                    help="CPU-baseline sample: whole samples per pixel of the same workload until this much time is spent")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="CPU-baseline sample: whole samples per pixel of the same frame until this much time is spent")
     ap.add_argument("--no-stage-times", action="store_true")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = the frame is gathered by RCCL over xGMI through the C ABI (one GPU per rank). gloo: rehearsal "
                          "only -- ranks may share one GPU, the gather goes through host memory")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="N = 1: run the RCCL branch anyway (unique id -> comm_init -> gather -> gathered) with a one-rank communicator")
     ap.add_argument("--dump", default=None, help="write the tone-mapped frame (PPM) here (rank 0)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, rng_mode, gpu_frame=None):
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD (torch.distributed.run), relay its
+    output and exit code. Nothing in this process has touched the GPU or imported torch (a process that has initialised
+    the GPU must never be replaced by exec on this pool; a child is always safe)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(args, rng_mode):
     """The oracle (kind "port": the build's own CPU restatement of the reference's chain; the reference's
     cpu_wavefront_pt has no source) timed on this box's host cores, OpenMP, on a bounded sample of the SAME
-    workload: same scene/seed/camera/size/bounces, fewer samples per pixel (Mrays/s is spp-invariant)."""
+    workload: same scene/seed/camera/size/bounces, the frame's first samples per pixel until --cpu-seconds are spent
+    (Mrays/s is spp-invariant). Returns (json object, samples rendered, their accumulated image)."""
     from oracle import oracle as O
     if args.scene == "mesh":
         o = O.mesh_oracle(args.width, args.height, args.triangles, seed=args.seed, max_wavefronts=args.bounces, rng_mode=rng_mode)
@@ -85,19 +112,14 @@ def cpu_baseline(args, rng_mode, gpu_frame=None):
         o.render_sample()
         spp += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or spp >= max(args.steps, 4):
+        if el >= args.cpu_seconds or spp >= args.spp:
             break
     rays = int(o.totals()[0])
     cores = O.lib().orc_num_threads()
     out = {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-           "sample": f"{spp} of the workload's {args.steps} samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
+           "sample": f"the first {spp} of the frame's {args.spp} samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
                      f"{rays} rays, {el:.1f} s, OpenMP x{cores})"}
-    # the oracle is the checker: when it got through all K samples in its time budget, its accumulated image is the
-    # image the timed GPU steps must have produced, bit for bit (outside the timed region, costs one comparison)
-    if gpu_frame is not None and spp == args.steps:
-        import numpy as np
-        same = np.array_equal(np.ascontiguousarray(o.accumulated()).view(np.uint32), np.ascontiguousarray(gpu_frame).view(np.uint32))
-        out["gpu_image_vs_oracle"] = "bit-identical" if same else "DIFFERENT"
+    image = o.accumulated().copy()
     o.close()
     # single-thread figure: the serial twin of the oracle on one sample per pixel of the same frame
     mk = O.mesh_oracle if args.scene == "mesh" else O.shirley_oracle
@@ -108,9 +130,10 @@ def cpu_baseline(args, rng_mode, gpu_frame=None):
     el1 = time.perf_counter() - t0
     out["single_thread"] = {"value": round(int(o1.totals()[0]) / el1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
                             "sample": f"1 sample per pixel, {int(o1.totals()[0])} rays, {el1:.1f} s"}
-    out["build"] = "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile)"
+    out["build"] = "gcc -O3 -ffp-contract=off (oracle/Makefile)"
+    out["march"] = "x86-64-v3 (not BASELINE.md's -march=native: the .so is built in the build container and travels to the GPU box)"
     o1.close()
-    return out
+    return out, spp, image
 
 
 def baseline_metric():
@@ -118,7 +141,7 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "Mrays/s (extend+shade) at 1920\u00d71080, 64 spp, 8 bounces; 1/2/4/8 GPU"
+        return "Mrays/s (extend+shade) at 1920×1080, 64 spp, 8 bounces; 1/2/4/8 GPU"
 
 
 def load_pmc(scene, variant):
@@ -137,6 +160,9 @@ def load_pmc(scene, variant):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # before torch or the GPU are touched
+
     import numpy as np
     import torch
     import wavefront_path_tracer_amd as W
@@ -145,14 +171,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available() or W.device_count() < 1:
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     rehearsal = args.dist_backend == "gloo"
-    gpu_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    n_dev = torch.cuda.device_count()
+    # one GPU per rank. With fewer GPUs than ranks the ranks wrap around: RCCL then refuses the communicator with its own
+    # "duplicate GPU" error and the run FAILS (only the gloo rehearsal may share a GPU)
+    gpu_index = local_rank % n_dev
     torch.cuda.set_device(gpu_index)
     dist = None
     if world > 1:
@@ -168,11 +194,12 @@ def main():
     rng_mode = W.RNG_DISPATCH if mode_name == "dispatch" else W.RNG_PIXEL
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
              (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0) |
-             (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0))
-    # samples in flight per launch: 64 at N=1 (32 / 64 / 128: 18.8 / 19.4 / 19.6 Grays/s on a 128-spp job: the late wavefronts are
-    # small, and a launch of few work items per workgroup ends on a long tail); each rank of N holds 1/N of the pixels, so it
-    # scales with N (up to the library's 128) to keep launches as large
-    batch = args.batch or min(128, 64 * world)
+             (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0) |
+             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0))
+    # samples in flight per launch = the whole frame's samples (64): the late wavefronts are small, and a launch of few work
+    # items per workgroup ends on a long tail (32 / 64 / 128 in flight: 18.8 / 19.4 / 19.6 Grays/s on a 128-spp job)
+    fused = not (args.split_shade or args.unfused)
+    batch = args.batch or min(args.spp, 128 if fused else 64)
     kw = dict(seed=args.seed, max_wavefronts=args.bounces, rng_mode=rng_mode, flags=flags, tile_rank=rank,
               tile_world=world, device=gpu_index, batch=batch)
     if args.scene == "mesh":
@@ -181,7 +208,7 @@ def main():
                       "the reference has no triangle code)")
     else:
         pt = W.shirley_path_tracer(args.width, args.height, **kw)
-        scene_name = f"Shirley random-spheres (scene.rs:48-107, seed {args.seed})" 
+        scene_name = f"Shirley random-spheres (scene.rs:48-107, seed {args.seed})"
 
     def sync():
         pt.synchronize()
@@ -189,8 +216,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    gather_path = "none" if world == 1 else ("gloo through host memory (REHEARSAL)" if rehearsal else "RCCL send/recv to rank 0 behind the C ABI")
-    if world > 1 and not rehearsal:
+    def fail(msg):
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(3)
+
+    use_rccl = (world > 1 and not rehearsal) or (world == 1 and args.force_rccl)
+    gather_path = "none" if not (world > 1 or use_rccl) else (
+        "gloo through host memory (REHEARSAL)" if not use_rccl else "RCCL send/recv to rank 0 behind the C ABI")
+    if use_rccl:
         # The RCCL bootstrap needs a socket interface; on one node the loopback always works (the data itself goes over xGMI)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         err = None
@@ -198,46 +233,46 @@ def main():
             uid = [W.comm_unique_id() if rank == 0 else None]
         except W.WfptError as e:
             uid, err = [None], str(e)
-        dist.broadcast_object_list(uid, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
         if uid[0] is not None:
             try:
                 pt.comm_init(uid[0], rank, world)  # collective: ncclCommInitRank on every rank's own GPU
             except W.WfptError as e:
                 err = str(e)
-        # every rank must take the same path: if the communicator could not be built anywhere, say so LOUDLY in the JSON line
-        # and move the slabs through host memory instead, so that the run still measures the sharded render
-        flags_t = torch.tensor([0 if (err is None and uid[0] is not None) else 1], dtype=torch.int32)
-        dist.all_reduce(flags_t, op=dist.ReduceOp.MAX)
-        if int(flags_t.item()):
-            rehearsal_gather = True
-            gather_path = f"FALLBACK: gloo through host memory, the RCCL communicator failed ({err or 'on another rank'})"
-            print(f"[bench rank {rank}] {gather_path}", file=sys.stderr, flush=True)
-        else:
-            rehearsal_gather = False
-    else:
-        rehearsal_gather = rehearsal
+        # every rank must take the same path: if the communicator could not be built on any rank, every rank stops
+        bad = 0 if (err is None and uid[0] is not None) else 1
+        if dist is not None:
+            flag_t = torch.tensor([bad], dtype=torch.int32)
+            dist.all_reduce(flag_t, op=dist.ReduceOp.MAX)
+            bad = int(flag_t.item())
+        if bad:
+            fail(f"the RCCL communicator could not be built ({err or 'failed on another rank'}); {world} ranks on {n_dev} GPU(s). "
+                 "One GPU per rank is required (use --dist-backend gloo only to rehearse the sharding on one GPU)")
 
     def gather():
+        if use_rccl:
+            pt.gather_accumulated()  # peers -> rank 0 over xGMI, de-interleaved on rank 0's GPU; asynchronous on the context's stream
+            return None
         if world == 1:
             return None
-        if rehearsal_gather:  # ranks share a GPU (which RCCL refuses) or RCCL is unusable: slabs go through host memory (gloo)
-            return tiles.gather_slabs(pt.accumulated(), rank, world, args.width, args.height)
-        pt.gather_accumulated()  # peers -> rank 0 over xGMI, de-interleaved on rank 0's GPU; asynchronous on the context's stream
-        return None
+        # rehearsal: ranks share a GPU (which RCCL refuses): slabs go through host memory (gloo)
+        return tiles.gather_slabs(pt.accumulated(), rank, world, args.width, args.height)
 
-    pt.render(args.warmup)
-    # prime (untimed) the captured launch shapes the timed K steps will replay: full batches + the remainder
-    for nb in {min(batch, args.steps), args.steps % batch}:
-        if nb:
-            pt.render(nb)
-    if world > 1:
-        gather()  # warm the communicator too
-    pt.reset_progress()  # the timed K steps are frames 1..K: the frames the oracle renders in the cpu_baseline leg
+    def render_frame(spp):
+        """One step: a whole frame of `spp` samples per pixel, frames 1..spp of RenderProgress, then the job's only collective."""
+        pt.reset_progress()
+        pt.render(spp)
+        return gather()
+
+    for _ in range(max(args.warmup, 1)):  # also primes (untimed) the captured launch shapes and warms the communicator
+        render_frame(args.spp)
     sync()
     rays0 = pt.totals().copy()
     t0 = time.perf_counter()
-    pt.render(args.steps)          # EXACTLY K steps
-    frame = gather()               # the job's only collective
+    frame = None
+    for _ in range(args.steps):        # EXACTLY K steps
+        frame = render_frame(args.spp)
     sync()
     elapsed = time.perf_counter() - t0
     rays = pt.totals() - rays0     # [rays traced by extend, hits, misses] on this rank
@@ -250,41 +285,53 @@ def main():
         rays_total = r.cpu().numpy().astype(np.uint64)
     else:
         rays_total = rays
-    if world == 1:
+    if use_rccl:
+        if rank == 0:
+            frame = pt.gathered()  # outside the timed region: the frame crosses PCIe only for the dump / the check
+    elif world == 1:
         frame = pt.accumulated()
-    elif not rehearsal_gather and rank == 0:
-        frame = pt.gathered()  # outside the timed region: the frame crosses PCIe only for the dump / the check
+    if world == 1 and args.force_rccl:  # the one-rank communicator's assembled frame must be the context's own image
+        if not np.array_equal(np.ascontiguousarray(frame).view(np.uint32), np.ascontiguousarray(pt.accumulated()).view(np.uint32)):
+            fail("RCCL branch: the gathered frame differs from the accumulated image")
 
-    # ---- per-stage times and the roofline of the dominant kernel: same K steps again with hipEvent pairs around
+    # ---- per-stage times and the roofline of the dominant kernel: the same K frames again with hipEvent pairs around
     # every launch on the context's stream (a second pass, so the events do not perturb `value`)
-    fused = not (args.split_shade or args.unfused)
     stage = None
     if not args.no_stage_times:
         ms = np.zeros(W.STAGE_COUNT, np.float64)
         launches = np.zeros(W.STAGE_COUNT, np.int64)
         r0, w0 = pt.totals().copy(), pt.wavefront_totals().astype(np.float64)
-        m, l = pt.render_timed(args.steps)  # same batching as pt.render
-        ms += m
-        launches += l
+        for _ in range(args.steps):
+            pt.reset_progress()
+            m, l = pt.render_timed(args.spp)  # same batching as pt.render
+            ms += m
+            launches += l
         rt = pt.totals() - r0
-        wt = pt.wavefront_totals().astype(np.float64) - w0  # rows (rays traced, hits, misses) per wavefront over these K steps
+        wt = pt.wavefront_totals().astype(np.float64) - w0  # rows (rays traced, hits, misses) per wavefront over these K frames
         shade_ms = float(sum(ms[W.STAGES[k]] for k in ("shade", "shade_lambertian", "shade_metal", "shade_dielectric")))
+        refill = fused and args.scene == "mesh" and not args.no_refill
         if fused:
-            # dominant kernel: the middle bounce launches = shade(b-1) + extend(b) + miss_kernel(b-1), b = 1 .. max-1.
+            # dominant kernel: the middle bounce launches = shade(b-1) + extend(b) [+ miss_kernel(b-1)], b = 1 .. max-1.
             # Algorithmic bytes = SURVEY 8(d)'s per-unit figures times the units those launches process.
-            kname, kstage = "bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)", "bounce"
+            kname = ("refill_kernel<middle> (shade + four-wide extend of one wavefront, dynamic lane refill)" if refill else
+                     "bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)")
+            kstage = "bounce"
             shaded, applied = wt[:-1, 1].sum(), wt[:-1, 2].sum()        # hits / misses of wavefronts 0 .. max-2
-            rays, hits_out, miss_out = wt[1:, 0].sum(), wt[1:, 1].sum(), wt[1:, 2].sum()
-            k_bytes = (B_SHADE_HIT * shaded + B_EXTEND_RAY * rays + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied)
-            # what the fused design itself has to move: record in (32), throughput RMW (24), record out (32) / miss out (8),
-            # applied miss (8 + 24) -- no extension-ray queue, no hit-queue gather
-            k_own = 56.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 32.0 * applied
-            chain_ms = float(sum(ms[W.STAGES[k]] for k in ("bounce_first", "bounce", "bounce_last", "scan")))
+            rays_k, hits_out, miss_out = wt[1:, 0].sum(), wt[1:, 1].sum(), wt[1:, 2].sum()
+            if refill:  # miss_kernel and the compaction are launches of their own there
+                k_bytes = B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out
+                k_own = 56.0 * shaded + 32.0 * rays_k  # record in (32) + throughput RMW (24); one dense 32-byte result per ray out
+            else:
+                k_bytes = (B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied)
+                # what the fused design itself has to move: record in (32), throughput RMW (2 x 16, padded pixels), record out
+                # (32) / miss out (8), applied miss (8 + 32) -- no extension-ray queue, no hit-queue gather
+                k_own = 64.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 40.0 * applied
+            chain_ms = float(sum(ms[W.STAGES[k]] for k in ("bounce_first", "bounce", "bounce_last", "scan", "compact", "miss_kernel")))
         else:
             kname, kstage = "extend_kernel", "extend"
             k_bytes = B_EXTEND_RAY * float(rt[0]) + B_EXTEND_HIT * float(rt[1]) + B_EXTEND_MISS * float(rt[2])
             k_own = k_bytes + 8.0 * float(rt[2])  # + (dir.y, pixel) handed to miss_kernel through the miss queue
-            chain_ms = float(ms[W.STAGES["extend"]] + ms[W.STAGES["scan"]]) + shade_ms
+            chain_ms = float(ms[W.STAGES["extend"]] + ms[W.STAGES["scan"]] + ms[W.STAGES["miss_kernel"]]) + shade_ms
         stage = {"ms": {k: round(float(ms[v]), 4) for k, v in W.STAGES.items() if launches[v]},
                  "launches": {k: int(launches[v]) for k, v in W.STAGES.items() if launches[v]},
                  "kname": kname, "k_ms": float(ms[W.STAGES[kstage]]), "k_n": int(launches[W.STAGES[kstage]]),
@@ -297,7 +344,7 @@ def main():
         return
 
     out = {
-        "metric": baseline_metric(),  # BASELINE.json's metric, verbatim; config.workload says what THIS run rendered (K = spp)
+        "metric": baseline_metric(),  # BASELINE.json's metric, verbatim; config.workload says what one step rendered
         "value": round(float(rays_total[0]) / elapsed / 1e6, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -309,16 +356,20 @@ def main():
         "vs_baseline": None,  # the reference publishes no number for this metric
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{scene_name}, {args.width}x{args.height}, {args.steps} spp, {args.bounces} bounces",
-                   "step": "one sample per pixel: generate_rays -> bounces x (extend, scan, shade, miss_kernel) -> accumulate",
+        "config": {"workload": f"{scene_name}, {args.width}x{args.height}, {args.spp} spp, {args.bounces} bounces",
+                   "step": (f"one frame: accumulation reset, {args.spp} samples per pixel (each generate_rays -> {args.bounces} x (extend, scan, "
+                            "shade, miss_kernel) -> accumulate)" + (", one gather of the frame to rank 0" if world > 1 else "")),
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
                    "loop": "fused bounce launches" if fused else "stage kernels one by one",
-                   "traversal": ("LDS-resident binary BVH" if args.scene == "shirley" else
-                                 ("binary BVH from HBM" if args.binary_bvh else "four-wide collapsed BVH (128-byte nodes) from HBM")),
+                   "traversal": (("LDS-resident binary BVH" + (", reference slab arithmetic (exact-traversal)" if args.exact_traversal else ""))
+                                 if args.scene == "shirley" and not args.no_lds_scene else
+                                 ("binary BVH from HBM" if (args.binary_bvh or args.scene == "shirley") else
+                                  "four-wide collapsed BVH (64-byte quantised nodes, top of the tree staged in LDS) from HBM")),
                    "launch": "direct" if args.no_graph else "hipGraph",
-                   "samples_in_flight": sorted({min(batch, args.steps), args.steps % batch} - {0}, reverse=True),
+                   "samples_in_flight": sorted({min(batch, args.spp), args.spp % batch} - {0}, reverse=True),
                    "parallelism": "single GPU" if world == 1 else
-                   f"pixel bands of 8 rows over {world} ranks + 1 gather ({gather_path})",
+                   f"pixel bands of 8 rows over {world} ranks + 1 gather per frame ({gather_path})",
+                   "gather": gather_path,
                    "rays_traced": int(rays_total[0])},
     }
     info = W.device_info(gpu_index)
@@ -335,33 +386,50 @@ def main():
             variant += "_norefill"
         if args.no_lds_scene:
             variant += "_nolds"
+        if args.exact_traversal:
+            variant += "_exact"
         pmc = load_pmc(args.scene, variant)
-        # PMC traffic is a property of (scene, loop variant): the profile stores HBM bytes per algorithmic byte of the
-        # same kernel on the same workload, scaled here by this run's algorithmic bytes per launch; null without a profile
-        ratio = (pmc or {}).get("hbm_bytes_per_algorithmic_byte")
-        out["roofline"] = {"kernel": stage["kname"], "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        # PMC counters cannot be collected inside a plain run: `traffic` and `secondary` come from the committed rocprofv3
+        # profile of THIS command (same scene, loop variant and samples in flight) and are labelled as such
+        same_shape = bool(pmc) and pmc.get("samples_in_flight") == min(batch, args.spp)
+        hbm_per_launch = (pmc or {}).get("hbm_bytes_per_launch")
+        out["roofline"] = {"kernel": stage["kname"],
+                           "bound": ("valu" if args.scene == "shirley" and not args.no_lds_scene else "l1"),
+                           "bound_note": ("bound by wave64 VALU issue (LDS-resident BVH, no HBM traffic for the scene); achieved / peak / frac are the "
+                                          "HBM figures BASELINE asks for, secondary holds the VALU figures (DESIGN.md section 4)"
+                                          if args.scene == "shirley" and not args.no_lds_scene else
+                                          "bound by the L1 -> register path of the per-lane node fetches with VALU issue close behind; "
+                                          "achieved / peak / frac are the HBM figures BASELINE asks for (DESIGN.md section 8)"),
+                           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": round(ratio * per_launch_bytes, 1) if ratio else None,
-                           "traffic_source": (pmc or {}).get("source"),
+                           "traffic": round(hbm_per_launch, 1) if (hbm_per_launch and same_shape) else None,
+                           "traffic_source": (f"from_profile: {pmc['source']} ({pmc.get('samples_in_flight')} samples in flight, rocprofv3 --pmc of this command)"
+                                              if (hbm_per_launch and same_shape) else None),
                            "peak_device": round(peak_device, 1),
                            "peak_device_source": f"hipDeviceProp_t: 2 x {info['memory_clock_khz']} kHz x {info['memory_bus_width_bits']} bit / 8",
                            "algorithmic_bytes_per_launch": round(per_launch_bytes, 1),
                            "fused_design_bytes_per_launch": round(stage["k_own"] / max(stage["k_n"], 1), 1),
-                           "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["k_n"],
-                           "note": ("traversal is VALU-issue bound (LDS-resident BVH), not HBM-bound; see DESIGN.md section 4"
-                                    if args.scene == "shirley" else
-                                    "BVH read from HBM / Infinity Cache through L2; bound by random-line throughput behind the L1 (DESIGN.md section 8)")}
-        if pmc and "secondary" in pmc:
-            out["roofline"]["secondary"] = pmc["secondary"]  # VALU occupancy, active lanes: measured under rocprofv3 --pmc
+                           "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["k_n"]}
+        if pmc and "secondary" in pmc and same_shape:
+            sec = dict(pmc["secondary"])
+            sec["source"] = f"from_profile: {pmc['source']} ({pmc.get('samples_in_flight')} samples in flight)"
+            out["roofline"]["secondary"] = sec
         out["stage_ms"] = stage["ms"]
         out["stage_launches"] = stage["launches"]
         out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, rng_mode, frame)
+        cb, n_cpu, cpu_image = cpu_baseline(args, rng_mode)
+        # the oracle is the checker: one UNTIMED frame of the samples it got through, rendered again by the GPU with the
+        # timed run's batching, must be its image bit for bit
+        pt.reset_progress()
+        pt.render(n_cpu)
+        same = np.array_equal(np.ascontiguousarray(cpu_image).view(np.uint32), np.ascontiguousarray(pt.accumulated()).view(np.uint32))
+        cb["gpu_image_vs_oracle"] = ("bit-identical" if same else "DIFFERENT") + f" ({n_cpu} spp frame)"
+        out["cpu_baseline"] = cb
     if args.dump and frame is not None:
         if hasattr(frame, "cpu"):
             frame = frame.cpu().numpy().reshape(-1, 3)
-        rgb = W.tonemap_rgb8(frame, args.steps)
+        rgb = W.tonemap_rgb8(frame, args.spp)
         with open(args.dump, "wb") as f:
             f.write(b"P6\n%d %d\n255\n" % (args.width, args.height))
             f.write(rgb.tobytes())

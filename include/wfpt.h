@@ -184,8 +184,15 @@ enum {
                                         four-wide collapse built at wfpt_create (same hits; for comparisons) */
     WFPT_FLAG_NO_REFILL = 1u << 4,   /* scenes too large for LDS: lanes keep their ray until the whole 512-ray segment is
                                         done (the fused bounce kernel) instead of taking new rays as they finish */
-    WFPT_FLAG_NO_LDS_SCENE = 1u << 5 /* treat the scene as too large for LDS even if it fits (experiments, tests of the
+    WFPT_FLAG_NO_LDS_SCENE = 1u << 5, /* treat the scene as too large for LDS even if it fits (experiments, tests of the
                                         HBM-resident traversal on small scenes) */
+    WFPT_FLAG_EXACT_TRAVERSAL = 1u << 6 /* trace_ray / hit_bvh_node exactly as extend.wgsl:72-183 writes them: slab planes
+                                        (b - o) * inv with min / max per axis, a missed box reports 1e30 (so the reference's
+                                        `1e30 > 1e30` descent into doubly-missed pairs happens), the binary tree walked as it
+                                        is. Default (flag clear): the same walk with a CONSERVATIVE box test (boxes grown by
+                                        more than the test's rounding error) -- same hits, fewer instructions; the library
+                                        falls back to the exact test by itself when a camera or an injected ray lies outside
+                                        the range that bound covers. Same images bit for bit; for bisecting and proofs. */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu
@@ -284,6 +291,17 @@ wfpt_ctx *wfpt_create_mesh(const wfpt_params *params,
                            const wfpt_gpu_camera *camera, const float inv_proj[16], const float view[16]);
 void wfpt_destroy(wfpt_ctx *ctx);
 const char *wfpt_last_error(const wfpt_ctx *ctx);
+
+/* Dynamic scenes (the reference builds its scene once, in PathTracer::new, path_tracer.rs:117-128):
+ * replaces the scene of a live context. `spheres` / `triangles` are reordered in place by the BVH build, as
+ * BVHTree::build_bvh_tree does (bvh.rs:182); the BVH is rebuilt on the context's device by wfpt_build_bvh_device /
+ * wfpt_build_bvh_triangles_device (byte-identical to bvh.rs:147-210; n_bins = 0 means 32), the traversal's derived data
+ * re-derived, and the accumulation and the frame counter reset like update_buffers does for a parameter change
+ * (path_tracer.rs:240-277). The primitive count and kind may change; queues and images keep their size. The context is
+ * unchanged if the arguments are refused; a HIP failure half way leaves it without a scene (only wfpt_destroy is safe). */
+int wfpt_update_scene(wfpt_ctx *ctx, wfpt_sphere *spheres, uint32_t n_spheres, const wfpt_material *materials, uint32_t n_materials);
+int wfpt_update_scene_mesh(wfpt_ctx *ctx, wfpt_triangle *triangles, uint32_t n_triangles, const wfpt_material *materials,
+                           uint32_t n_materials, uint32_t n_bins);
 
 /* Image chunking on one GPU (the reference's to-do "split rendering of image into chunks so that the buffers aren't so
  * big", README.md:20): renders n_samples of the whole frame as `chunks` band-interleaved slabs, one context after the

@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
-COMMON = ["--steps", "6", "--warmup", "2", "--width", "400", "--height", "225", "--bounces", "5", "--no-stage-times", "--no-cpu-baseline"]
+COMMON = ["--steps", "2", "--warmup", "1", "--spp", "6", "--width", "400", "--height", "225", "--bounces", "5", "--no-stage-times", "--no-cpu-baseline"]
 
 
 def last_json_line(text):
@@ -37,3 +37,35 @@ def test_two_rank_rehearsal_equals_single_rank(gpu, tmp_path):
         assert key in b
     assert a["config"]["rays_traced"] == b["config"]["rays_traced"]  # the same rays, split over two ranks
     assert one.read_bytes() == two.read_bytes()
+
+
+def test_rccl_branch_of_bench_with_a_one_rank_communicator(gpu):
+    """bench.py's N > 1 data path -- wfpt_comm_unique_id -> wfpt_comm_init -> wfpt_gather_accumulated per frame ->
+    wfpt_read_gathered -- executed at world 1 (`--force-rccl`), so that it has run before an 8-GPU box sees it. bench.py itself
+    compares the gathered frame with the accumulated image and fails on a difference."""
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, "--rng-mode", "pixel", "--force-rccl"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json_line(r.stdout)
+    assert line["n_gpus"] == 1 and "RCCL" in line["config"]["gather"]
+    assert line["config"]["samples_in_flight"] == [6] and "6 spp" in line["config"]["workload"]
+
+
+def test_bench_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (torch.distributed.run as a child). On a box with
+    two GPUs the line comes back; on a one-GPU box the run must fail at RCCL's own refusal of two ranks on one device -- with
+    a non-zero exit code and that reason on stderr -- not at an argument check."""
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *COMMON], capture_output=True, text=True, env=env,
+                       cwd=ROOT, timeout=600)
+    if gpu.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = last_json_line(r.stdout)
+        assert line["n_gpus"] == 2 and "RCCL" in line["config"]["gather"]
+    else:
+        assert r.returncode != 0
+        assert "RCCL communicator could not be built" in r.stderr, r.stderr[-3000:]
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no number from a run that did not shard over GPUs

@@ -116,7 +116,8 @@ def test_kernel_literals(ref):
     # the oracle keeps the reference's box-miss value (extend.wgsl:181); the device deliberately reports a LARGER one, so that a
     # pair of missed boxes is not walked down while `nearest` still holds the no-hit sentinel of the same value
     assert re.search(r"return 1e30f;", function_body(orc, "hit_bvh_node"))
-    assert re.search(r"\? kBoxMiss : tmin", function_body(dev, "hit_bvh_node"))
+    # WFPT_FLAG_EXACT_TRAVERSAL (template EXACT) restores the reference's value on the device too
+    assert re.search(r"\? \(EXACT \? 1e30f : kBoxMiss\) : tmin", function_body(dev, "hit_bvh_node"))
     m = re.search(r"constexpr float kBoxMiss = ([0-9.e+]+)f;", dev)
     assert m and float(m.group(1)) > ex["box_miss"]["value"] and np.isfinite(np.float32(m.group(1)))
 

@@ -1,72 +1,196 @@
-// tools/microbench_valu.hip -- hipcc --offload-arch=gfx950 -O3 -o build/valu tools/microbench_valu.hip
-// What does one SIMD of gfx950 sustain in wave64 VALU instructions per cycle, for the instruction kinds the traversal
-// loop is made of (fp32 fma / min / max3 / compare + select), with 1 .. 8 waves per SIMD? The traversal's PMC profile
-// reads SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU (in quad-cycles): is the kernel at the VALU issue ceiling or at half of it?
+// tools/microbench_valu.hip -- hipcc --offload-arch=gfx950 -O3 -o build/valu tools/microbench_valu.hip && build/valu
+//
+// What does one SIMD of gfx950 sustain, in SHADER CYCLES per wave64 instruction, for each instruction class of the
+// traversal's hot loop, with 1 .. 8 waves per SIMD? Round 2's version timed short launches with hipEvents and reported
+// "cycles at the nominal 2.4 GHz"; it could not tell a 2-cycle pipe at a throttled clock from a 3-cycle pipe at full
+// clock. This one measures inside the kernel:
+//   cycles = delta s_memtime (shader clock ticks) around a loop of 64 INDEPENDENT instructions per trip (16 registers x 4),
+//   clock  = delta s_memtime / delta s_memrealtime x 100 MHz (s_memrealtime = wall_clock64(), a constant 100 MHz counter),
+// after >= 0.7 s of back-to-back launches of the same kernel so that the chip sits in the DVFS state the load gives it
+// (MI355X_MICROARCH.md "DVFS give-back" item 6). Reported per class: cycles per instruction per SIMD (= wave cycles /
+// (waves per SIMD x instructions)), the clock held, and ns per instruction per SIMD (what a kernel's wall time sees).
+// Every instruction is inline asm on registers: the compiler can neither fuse, pack nor drop any of them.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+#include <string>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int kUnroll = 16; // independent chains per lane
+struct Stamp { unsigned long long cycles, real; };
+typedef float v4f __attribute__((ext_vector_type(4))); // a 128-bit VGPR tuple inline asm can name
 
-// MODE 0: v_fma_f32   1: v_min_f32 / v_max_f32   2: v_max3_f32 / v_min3_f32   3: v_cmp + v_cndmask   4: the slab-test mix
-template <int MODE> __global__ __launch_bounds__(256) void kern(float *out, uint32_t iters, float a, float b) {
-    float x[kUnroll];
+enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW, N_KINDS };
+
+// one instruction of the class on register x (a, b: loop-invariant VGPRs; m: an SGPR pair holding a lane mask)
+#define I_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_MIN(x) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_MAX(x) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(b))
+#define I_MAX3(x) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_MIN3(x) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_CND(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "s"(m))
+#define I_CMP(x) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m2) : "v"(x), "v"(a))
+#define I_RCP(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x))
+#define I_SQRT(x) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x))
+#define I_ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(a))
+#define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc))
+
+#define REP16(OP) OP(x[0]); OP(x[1]); OP(x[2]); OP(x[3]); OP(x[4]); OP(x[5]); OP(x[6]); OP(x[7]); OP(x[8]); OP(x[9]); OP(x[10]); OP(x[11]); OP(x[12]); OP(x[13]); OP(x[14]); OP(x[15])
+
+template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, float *sink, uint32_t trips, float fa, float fb) {
+    __shared__ float4 s_tab[1024]; // 16 KB: ds_read_b128 targets (FMA_DSREAD, VISIT_*)
+    for (uint32_t i = threadIdx.x; i < 1024; i += 256) s_tab[i] = make_float4(fa, fb, fa, fb);
+    __syncthreads();
+    float x[16];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) x[k] = a + static_cast<float>(threadIdx.x + k);
-    for (uint32_t it = 0; it < iters; ++it) {
+    for (int k = 0; k < 16; ++k) x[k] = fa + static_cast<float>((threadIdx.x * 16 + k) & 1023) * 1e-3f;
+    float a = fa, b = fb;
+    unsigned long long m = 0x5555aaaa3333ccccull, m2 = 0;
+    uint32_t sc = 0;
+    uint32_t addr = (threadIdx.x * 37u & 255u) * 64u; // per-lane node pair, 64 B apart
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t it = 0; it < trips; ++it) {
+        if (KIND == FMA) { REP16(I_FMA); REP16(I_FMA); REP16(I_FMA); REP16(I_FMA); }
+        if (KIND == MINMAX) { REP16(I_MIN); REP16(I_MAX); REP16(I_MIN); REP16(I_MAX); }
+        if (KIND == MAX3) { REP16(I_MAX3); REP16(I_MIN3); REP16(I_MAX3); REP16(I_MIN3); }
+        if (KIND == CNDMASK) { REP16(I_CND); REP16(I_CND); REP16(I_CND); REP16(I_CND); }
+        if (KIND == CMP) { REP16(I_CMP); REP16(I_CMP); REP16(I_CMP); REP16(I_CMP); }
+        if (KIND == CMP_CND) { // compare -> select pairs, the select reads the mask the compare just wrote (32 + 32)
 #pragma unroll
-        for (int k = 0; k < kUnroll; ++k) {
-            if (MODE == 0) x[k] = __builtin_fmaf(x[k], a, b);
-            if (MODE == 1) x[k] = (k & 1) ? __builtin_fminf(x[k], a + x[(k + 1) % kUnroll]) : __builtin_fmaxf(x[k], b);
-            if (MODE == 2) x[k] = __builtin_fmaxf(__builtin_fmaxf(x[k], a), x[(k + 3) % kUnroll]);
-            if (MODE == 3) x[k] = x[k] > x[(k + 5) % kUnroll] ? a : x[k] + b;
-            if (MODE == 4) { // fma, fma, min, max per axis pair as in hit_bvh_node_fma
-                const float t0 = __builtin_fmaf(x[k], a, b), t1 = __builtin_fmaf(x[(k + 1) % kUnroll], a, b);
-                x[k] = __builtin_fminf(t0, t1) + __builtin_fmaxf(t0, t1) * 1e-9f;
+            for (int k = 0; k < 32; ++k) {
+                asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m2) : "v"(x[k & 15]), "v"(a));
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[(k + 8) & 15]) : "v"(b), "s"(m2));
             }
         }
-    }
-    float s = 0.0f;
+        if (KIND == RCP) { REP16(I_RCP); REP16(I_RCP); REP16(I_RCP); REP16(I_RCP); }
+        if (KIND == SQRT) { REP16(I_SQRT); REP16(I_SQRT); REP16(I_SQRT); REP16(I_SQRT); }
+        if (KIND == ADDU) { REP16(I_ADDU); REP16(I_ADDU); REP16(I_ADDU); REP16(I_ADDU); }
+        if (KIND == LSHLADD) { REP16(I_LSHLADD); REP16(I_LSHLADD); REP16(I_LSHLADD); REP16(I_LSHLADD); }
+        if (KIND == FMA_DEP) { // ONE dependent chain: latency, not throughput
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) s += x[k];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+            for (int k = 0; k < 64; ++k) I_FMA(x[0]);
+        }
+        if (KIND == FMA_SALU) { // 64 v_fma with a scalar add after every second one (the traversal has 1 SALU per 3 VALU)
+#pragma unroll
+            for (int k = 0; k < 64; ++k) { I_FMA(x[k & 15]); if (k & 1) I_SALU(); }
+        }
+        if (KIND == FMA_DSREAD) { // 64 v_fma + 4 ds_read_b128 per 64 (the node pair of one visit), waited for once per trip
+            v4f n0, n1, n2, n3;
+            asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48"
+                         : "=v"(n0), "=v"(n1), "=v"(n2), "=v"(n3) : "v"(addr));
+            REP16(I_FMA); REP16(I_FMA); REP16(I_FMA); REP16(I_FMA);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            asm volatile("" ::"v"(n0), "v"(n1), "v"(n2), "v"(n3));
+            addr = (addr + 64u * 7u) & 16383u & ~63u;
+        }
+        if (KIND == VISIT_OLD || KIND == VISIT_NEW) {
+            // The instruction mix of one inner-node visit of the LDS traversal, as a DEPENDENT computation the way the kernel
+            // has it: 4 ds_read_b128 -> wait -> two slab tests -> ordering -> descent (the address of the next trip depends on
+            // the result). OLD: 6 fma + 3 min + 3 max + min3 + max3 per box (round 2). NEW: 9 fma + max3 + min3 per box
+            // (centre / half-extent planes, no per-axis min / max). One wave makes ONE visit per trip: with W waves per SIMD this
+            // is what the real kernel does, minus divergence.
+            v4f n0, n1, n2, n3;
+            asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)"
+                         : "=v"(n0), "=v"(n1), "=v"(n2), "=v"(n3) : "v"(addr));
+            float tl, tr;
+            const float ix = a, iy = b, iz = x[1], nox = x[2], noy = x[3], noz = x[4], nearest = x[5];
+            if (KIND == VISIT_OLD) {
+                auto box = [&](v4f lo, v4f hi) {
+                    float t1 = __builtin_fmaf(lo.x, ix, nox), t2 = __builtin_fmaf(hi.x, ix, nox);
+                    float tmin = __builtin_fminf(t1, t2), tmax = __builtin_fmaxf(t1, t2);
+                    t1 = __builtin_fmaf(lo.y, iy, noy); t2 = __builtin_fmaf(hi.y, iy, noy);
+                    tmin = __builtin_fmaxf(__builtin_fminf(t1, t2), tmin); tmax = __builtin_fminf(__builtin_fmaxf(t1, t2), tmax);
+                    t1 = __builtin_fmaf(lo.z, iz, noz); t2 = __builtin_fmaf(hi.z, iz, noz);
+                    tmin = __builtin_fmaxf(__builtin_fminf(t1, t2), tmin); tmax = __builtin_fminf(__builtin_fmaxf(t1, t2), tmax);
+                    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 3e38f : tmin;
+                };
+                tl = box(n0, n1); tr = box(n2, n3);
+            } else {
+                const float ax = __builtin_fabsf(ix), ay = __builtin_fabsf(iy), az = __builtin_fabsf(iz);
+                auto box = [&](v4f c, v4f h) {
+                    const float cx = __builtin_fmaf(c.x, ix, nox), cy = __builtin_fmaf(c.y, iy, noy), cz = __builtin_fmaf(c.z, iz, noz);
+                    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(h.x, -ax, cx), __builtin_fmaf(h.y, -ay, cy)), __builtin_fmaf(h.z, -az, cz));
+                    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaf(h.x, ax, cx), __builtin_fmaf(h.y, ay, cy)), __builtin_fmaf(h.z, az, cz));
+                    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? 3e38f : tmin;
+                };
+                tl = box(n0, n1); tr = box(n2, n3);
+            }
+            const bool swap = tl > tr;
+            const float tnear = swap ? tr : tl, tfar = swap ? tl : tr;
+            uint32_t next = __float_as_uint(swap ? n2.w : n0.w);
+            if (tnear > nearest) next ^= 0x40u; // "pop": some other pair
+            x[6] = x[6] + ((tfar < nearest) ? 1.0f : 0.0f);
+            addr = (next * 64u + addr + 64u) & 16383u & ~63u;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = static_cast<float>(m2 & 1) + static_cast<float>(sc) + static_cast<float>(addr) + s_tab[threadIdx.x].x; // (keeps s_tab allocated, at LDS offset 0)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += x[k];
+    if (s == 123.456f) sink[0] = s; // keeps everything live, never true
+    if ((threadIdx.x & 63u) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = {t1 - t0, r1 - r0};
 }
 
-template <int MODE> int run(const char *name, int insts_per_iter_per_chain, float *d_out, int cus) {
-    const uint32_t iters = 4096;
+struct Row { std::string name; int insts_per_trip; };
+
+template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_out, float *d_sink, int cus) {
     for (int waves_per_simd : {1, 2, 4, 8}) {
-        // 256-thread blocks = 4 waves = one per SIMD; waves_per_simd blocks per CU
-        const int blocks = cus * waves_per_simd;
+        const int blocks = cus * waves_per_simd; // 256-thread blocks = 4 waves = one per SIMD; waves_per_simd blocks per CU
+        // pick the trip count for ~8 ms launches, then hold the load for >= 0.7 s before the measured launches
+        uint32_t trips = 2000;
+        auto launch = [&](uint32_t n) { hipLaunchKernelGGL(kern<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, n, 1.0001f, 0.5f); };
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(kern<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 64u, 1.0001f, 0.5f); // warm
+        CK(hipEventRecord(e0)); launch(trips); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        trips = static_cast<uint32_t>(std::min(4.0e6, std::max(2000.0, trips * 8.0 / std::max(ms, 0.01f))));
+        float held = 0;
+        while (held < 700.0f) {
+            CK(hipEventRecord(e0)); for (int k = 0; k < 8; ++k) launch(trips); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); held += ms;
+        }
+        launch(trips);
         CK(hipDeviceSynchronize());
-        CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0001f, 0.5f);
-        CK(hipEventRecord(e1));
-        CK(hipEventSynchronize(e1));
-        float ms = 0;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        const double wave_insts = static_cast<double>(iters) * kUnroll * insts_per_iter_per_chain * waves_per_simd; // per SIMD
-        // cycles per wave64 instruction per SIMD, at the nominal 2.4 GHz (the chip may clock lower under load)
-        printf("%-28s waves/SIMD %d: %8.3f ms  %6.2f cycles/instr/SIMD @2.4GHz\n", name, waves_per_simd, ms,
-               ms * 1e-3 * 2.4e9 / wave_insts);
+        std::vector<Stamp> h(static_cast<size_t>(blocks) * 4);
+        CK(hipMemcpy(h.data(), d_out, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
+        std::vector<double> cyc, clk;
+        for (const Stamp &s : h) { cyc.push_back(static_cast<double>(s.cycles)); clk.push_back(s.real ? 1e8 * s.cycles / s.real : 0.0); }
+        std::nth_element(cyc.begin(), cyc.begin() + cyc.size() / 2, cyc.end());
+        std::nth_element(clk.begin(), clk.begin() + clk.size() / 2, clk.end());
+        const double c = cyc[cyc.size() / 2], f = clk[clk.size() / 2];
+        const double per_simd = c / (static_cast<double>(trips) * insts_per_trip * waves_per_simd);
+        printf("%-34s waves/SIMD %d: %7.3f cycles/instr/SIMD  (one wave: %6.2f cycles/instr)  clock %.3f GHz  %6.3f ns/instr/SIMD\n", name,
+               waves_per_simd, per_simd, c / (trips * insts_per_trip), f * 1e-9, per_simd / (f * 1e-9));
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
-    return 0;
 }
 
 int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    float *d_out;
-    CK(hipMalloc(&d_out, sizeof(float) * 256 * cus * 8));
-    printf("device: %s, %d CUs\n", prop.name, cus);
-    if (run<0>("v_fma_f32", 1, d_out, cus)) return 1;
-    if (run<1>("v_min/v_max (+add)", 1, d_out, cus)) return 1;  // odd chains carry an extra add: ~1.5 per chain step
-    if (run<2>("v_max3_f32", 1, d_out, cus)) return 1;
-    if (run<3>("v_cmp + v_add + v_cndmask", 3, d_out, cus)) return 1;
-    if (run<4>("2 fma + min + max + fma", 5, d_out, cus)) return 1;
+    Stamp *d_out;
+    float *d_sink;
+    CK(hipMalloc(&d_out, sizeof(Stamp) * 4 * cus * 8));
+    CK(hipMalloc(&d_sink, 64));
+    printf("device: %s, %d CUs; cycles = s_memtime ticks, clock = s_memtime / s_memrealtime x 100 MHz, medians over all waves\n", prop.name, cus);
+    run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);
+    run<MINMAX>("v_min_f32 / v_max_f32", 64, d_out, d_sink, cus);
+    run<MAX3>("v_max3_f32 / v_min3_f32", 64, d_out, d_sink, cus);
+    run<CNDMASK>("v_cndmask_b32 (sgpr mask)", 64, d_out, d_sink, cus);
+    run<CMP>("v_cmp_gt_f32 -> sgpr", 64, d_out, d_sink, cus);
+    run<CMP_CND>("v_cmp -> v_cndmask pairs", 64, d_out, d_sink, cus);
+    run<RCP>("v_rcp_f32", 64, d_out, d_sink, cus);
+    run<SQRT>("v_sqrt_f32", 64, d_out, d_sink, cus);
+    run<ADDU>("v_add_u32", 64, d_out, d_sink, cus);
+    run<LSHLADD>("v_lshl_add_u32", 64, d_out, d_sink, cus);
+    run<FMA_DEP>("v_fma_f32, ONE dependent chain", 64, d_out, d_sink, cus);
+    run<FMA_SALU>("64 v_fma + 32 s_add (per VALU)", 64, d_out, d_sink, cus);
+    run<FMA_DSREAD>("64 v_fma + 4 ds_read_b128 (per VALU)", 64, d_out, d_sink, cus);
+    run<VISIT_OLD>("visit, min/max planes (per VISIT)", 1, d_out, d_sink, cus);
+    run<VISIT_NEW>("visit, centre/half planes (per VISIT)", 1, d_out, d_sink, cus);
     return 0;
 }

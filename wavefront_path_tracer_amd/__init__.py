@@ -24,14 +24,14 @@ from . import _build
 
 __all__ = ["SPP", "SPF", "Scene", "BVHTree", "Camera", "CameraController", "ProjectionMatrix", "GPUFrameBuffer",
            "RenderParameters", "RenderProgress", "Kernel", "PathTracer", "WfptError", "workgroup_size_64",
-           "RNG_DISPATCH", "RNG_PIXEL", "FLAG_SPLIT_SHADE", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "FLAG_BINARY_BVH", "FLAG_NO_REFILL", "FLAG_NO_LDS_SCENE", "STAGES", "lib", "build",
+           "RNG_DISPATCH", "RNG_PIXEL", "FLAG_SPLIT_SHADE", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "FLAG_BINARY_BVH", "FLAG_NO_REFILL", "FLAG_NO_LDS_SCENE", "FLAG_EXACT_TRAVERSAL", "STAGES", "lib", "build",
            "tonemap_rgb8", "selftest_math", "device_count"]
 
 SPP = 10  # wavefront_common/src/parameters.rs:4
 SPF = 1   # wavefront_common/src/parameters.rs:5
 
 RNG_DISPATCH, RNG_PIXEL = 0, 1
-FLAG_SPLIT_SHADE, FLAG_NO_GRAPH, FLAG_UNFUSED, FLAG_BINARY_BVH, FLAG_NO_REFILL, FLAG_NO_LDS_SCENE = 1, 2, 4, 8, 16, 32
+FLAG_SPLIT_SHADE, FLAG_NO_GRAPH, FLAG_UNFUSED, FLAG_BINARY_BVH, FLAG_NO_REFILL, FLAG_NO_LDS_SCENE, FLAG_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32, 64
 INACTIVE_PIXEL = 0xFFFFFFFF
 # kernel.rs:32 loads shaders/{name}.wgsl; these are the stage names (path_tracer.rs:162,167,175,180,185)
 STAGES = {"generate_rays": 0, "extend": 1, "shade": 2, "miss_kernel": 3, "accumulate": 4,
@@ -95,6 +95,31 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _agree_on_hip_runtime():
+    """libwfpt.so needs `libamdhip64.so.7`; a PyTorch ROCm wheel ships its own copy of that runtime (with its own HSA
+    runtime beside it) under the same SONAME. One process can initialise the GPU through one HIP/HSA pair only: with the
+    system copy mapped first, a later `import torch` would bring a second HSA runtime along and find "No HIP GPUs". So when a
+    PyTorch ROCm wheel is installed (whether or not it has been, or ever will be, imported) the copy it ships is the one
+    mapped first, by its file name: whichever of torch and this package loads first, both end up on the same runtime. Nothing
+    of torch is imported or executed here; hosts without PyTorch (C, C++, Rust) are not concerned."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # its runtime is already mapped; libwfpt.so's NEEDED entry resolves to it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime; `import torch` before this package still works as before
+
+
 def _lib_loaded():
     return _lib is not None
 
@@ -108,6 +133,7 @@ def lib():
     if not os.path.exists(path):
         raise WfptError(-5, f"{path} is missing: run wavefront_path_tracer_amd.build() "
                             "(python -m wavefront_path_tracer_amd._build); there is no CPU fallback")
+    _agree_on_hip_runtime()
     L = C.CDLL(path)
     vp, u32, i32, f32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
     sig = {
@@ -134,6 +160,8 @@ def lib():
         "wfpt_device_count": (i32, []),
         "wfpt_create": (vp, [C.POINTER(_Params), vp, u32, vp, u32, vp, u32, vp, vp, vp]),
         "wfpt_destroy": (None, [vp]),
+        "wfpt_update_scene": (i32, [vp, vp, u32, vp, u32]),
+        "wfpt_update_scene_mesh": (i32, [vp, vp, u32, vp, u32, u32]),
         "wfpt_last_error": (C.c_char_p, [vp]),
         "wfpt_set_frame": (i32, [vp, C.POINTER(GPUFrameBuffer)]),
         "wfpt_update_render_parameters": (i32, [vp, u32, u32, vp, vp, vp]),
@@ -651,6 +679,19 @@ class PathTracer:
         self.width, self.height = w, h
         self.n_pixels = lib().wfpt_n_pixels(self.handle)
         rp.reset()
+        self.render_progress.reset()
+
+    def update_scene(self, scene, mesh_bins=32):
+        """Build extension (dynamic scenes): replaces the scene of this live context. The BVH is rebuilt on the device
+        (reordering scene.spheres / scene.triangles in place, like PathTracer::new does, path_tracer.rs:117-118) and the
+        accumulation restarts at frame 1 (update_buffers, path_tracer.rs:240-277)."""
+        if scene.triangles is not None:
+            self._check(lib().wfpt_update_scene_mesh(self.handle, _p(scene.triangles), len(scene.triangles), _p(scene.materials),
+                                                     len(scene.materials), mesh_bins))
+        else:
+            self._check(lib().wfpt_update_scene(self.handle, _p(scene.spheres), len(scene.spheres), _p(scene.materials),
+                                                len(scene.materials)))
+        self.scene = scene
         self.render_progress.reset()
 
     def set_frame(self, frame):

@@ -22,6 +22,7 @@ using namespace wfpt;
 
 namespace {
 thread_local std::string g_last_error;
+thread_local int g_last_status = 0; // status of the last failure on this thread (wfpt_create returns a pointer, not a code)
 
 struct StageTimer {
     hipEvent_t start = nullptr, stop = nullptr;
@@ -51,7 +52,8 @@ struct wfpt_ctx {
     uint32_t capacity = 0;      // ray-queue slots (multiple of kChunk)
     uint32_t n_chunks_max = 0;
     uint32_t batch_max = 1;     // samples kept in flight by the device-resident loop
-    size_t image_floats = 0;    // floats per image slice
+    size_t image_floats = 0;    // floats per image slice (one float4 per pixel: r, g, b, unused)
+    size_t acc_floats = 0;      // floats of `accumulated` (the reference's stride-12 layout)
     uint32_t cus = 0, blocks_per_cu = 1;
     uint32_t last_slot = 0;     // batch slice that holds the most recent sample's bounce table
     bool has_inactive = false;
@@ -84,11 +86,17 @@ struct wfpt_ctx {
     float *image = nullptr, *accumulated = nullptr;
     Control *ctl = nullptr;
     CameraDev *camera = nullptr;
+    wfpt_gpu_camera h_camera{};      // host copy (the conservative traversal's range check, wfpt_update_scene)
     wfpt_bvh_node *d_nodes = nullptr;
     float4 *d_sphere_geom = nullptr;
     uint16_t *d_pair_parent = nullptr;
     uint32_t *d_pair_parent32 = nullptr;
     float4 *d_nodes4 = nullptr;      // HBM-resident scenes: the tree collapsed into four-wide nodes
+    float4 *d_nodes_ch = nullptr;    // LDS-resident scenes: conservative (centre, half-extent) boxes, see build_nodes_ch
+    float extent[3] = {0, 0, 0};     // per axis: the |coordinate| bound the conservative margin was sized for (origins up to 4x)
+    bool ch_ok = false;              // nodes_ch exists (LDS scene, finite boxes)
+    bool far_rays = false;           // wfpt_write_rays injected an origin beyond 4 x extent: the stage API's extend goes exact
+    size_t gather_frame_floats = 0, gather_stage_floats = 0; // allocated sizes of the two gather buffers
     uint32_t *d_stack_spill = nullptr;
     uint32_t depth4 = 0;
     wfpt_sphere *d_spheres = nullptr;
@@ -113,6 +121,7 @@ namespace {
 int fail(wfpt_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
     g_last_error = msg;
+    g_last_status = code;
     return code;
 }
 int hip_fail(wfpt_ctx *c, hipError_t e, const char *what) {
@@ -303,7 +312,7 @@ AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping,
     a.image = c->image;
     a.accumulated = c->accumulated;
     a.ctl = c->ctl;
-    a.n_floats = 3u * std::min(n_pixels, c->n_pixels);
+    a.n_pixels = std::min(n_pixels, c->n_pixels);
     a.bookkeeping = bookkeeping ? 1u : 0u;
     return a;
 }
@@ -476,8 +485,7 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
 int ensure_device_frame(wfpt_ctx *c) {
     if (c->dev_frame_valid) return WFPT_OK;
     const wfpt_frame_buffer f{c->width, c->height, c->progress_frame + 1u, 0u}; // parameters.rs:78-83; pt:296
-    WFPT_HIP(c, hipMemcpyAsync(&c->ctl->frame, &f, sizeof f, hipMemcpyHostToDevice, c->stream));
-    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, launch_set_frame(c->ctl, f, c->stream)); // on the stream: frames can be queued back to back without a host sync
     c->dev_frame_valid = true;
     return WFPT_OK;
 }
@@ -540,6 +548,201 @@ int stage_end(wfpt_ctx *c, int stage) {
     return WFPT_OK;
 }
 
+// ---------------------------------------------------------------- scene upload (wfpt_create, wfpt_update_scene)
+// The conservative boxes of trace_ray_conservative (wfpt_kernels.hip): node i as (centre | left_first), (half-extent |
+// prim_count). [c - h, c + h] encloses the caller's box, and h is then grown by margin = 2^-19 * extent per axis, where
+// extent >= every |coordinate| of the scene on that axis and >= a quarter of the camera's. The device computes, per axis,
+//   tc = fl(c b + nox), nox = -fl(o b);  t_entry = fl(tc - h |b|), t_exit = fl(tc + h |b|)      (b = clamped 1 / d)
+// whose errors against the exact ((c -+ h) - o) b are at most 2^-24 (3 |o| + 2 |c| + h) |b| <= 2^-24 * 15 extent * |b| for
+// |o| <= 4 extent, |c|, h <= extent: less than half of margin * |b|. So the computed entry distance never exceeds the
+// exact box's and the computed exit distance never falls below it: the test can only say "enter" more often than the
+// reference's (ex:164-183), never less. Returns false (=> the exact test is used) when a box is not finite.
+bool build_nodes_ch(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float cam_reach[3], std::vector<float4> &out, float extent[3]) {
+    auto up = [](double v) { // smallest float >= v
+        float f = static_cast<float>(v);
+        if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
+        return f;
+    };
+    for (int ax = 0; ax < 3; ++ax) {
+        float e = 0.25f * cam_reach[ax];
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            if (i == 1) continue; // the pad slot (bvh.rs:160-161)
+            const float lo = nodes[i].aabb_min[ax], hi = nodes[i].aabb_max[ax];
+            if (!std::isfinite(lo) || !std::isfinite(hi) || hi < lo) return false;
+            e = std::max(e, std::max(std::fabs(lo), std::fabs(hi)));
+        }
+        if (!(e < 1e30f)) return false;
+        extent[ax] = e;
+    }
+    out.resize(2 * static_cast<size_t>(n_nodes));
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        float c3[3], h3[3];
+        for (int ax = 0; ax < 3; ++ax) {
+            const double lo = nodes[i].aabb_min[ax], hi = nodes[i].aabb_max[ax];
+            const float c = static_cast<float>(0.5 * (lo + hi));
+            const double h = std::max(static_cast<double>(c) - lo, hi - static_cast<double>(c)); // exact in double
+            c3[ax] = c;
+            h3[ax] = up(static_cast<double>(up(h)) + std::ldexp(static_cast<double>(extent[ax]), -19));
+        }
+        float lf, pc;
+        std::memcpy(&lf, &nodes[i].left_first, 4);
+        std::memcpy(&pc, &nodes[i].prim_count, 4);
+        out[2 * i] = make_float4(c3[0], c3[1], c3[2], lf);
+        out[2 * i + 1] = make_float4(h3[0], h3[1], h3[2], pc);
+    }
+    return true;
+}
+
+// ray origins the camera can produce: |position| + the lens radius (gr:73-79), per axis
+void camera_reach(const wfpt_gpu_camera &cam, float reach[3]) {
+    const float r = cam.defocus_radius > 0.0f ? cam.defocus_radius : 0.0f;
+    for (int ax = 0; ax < 3; ++ax) reach[ax] = std::fabs(cam.position[ax]) + r;
+}
+
+// Which box test the traversal kernels run: the reference's own (WFPT_FLAG_EXACT_TRAVERSAL, or whenever the conservative
+// boxes' error bound does not cover the rays at hand) or the conservative one.
+void decide_exact(wfpt_ctx *c, const float cam_reach[3]) {
+    bool exact = (c->p.flags & WFPT_FLAG_EXACT_TRAVERSAL) != 0 || (c->scene.lds_scene && !c->ch_ok) || c->far_rays;
+    for (int ax = 0; ax < 3 && !exact && c->ch_ok; ++ax)
+        if (!(cam_reach[ax] <= 4.0f * c->extent[ax])) exact = true;
+    c->scene.exact = exact ? 1u : 0u;
+}
+
+void free_scene(wfpt_ctx *c) {
+    void *bufs[] = {c->d_shade_rec, c->d_nodes, c->d_nodes4, c->d_nodes_ch, c->d_stack_spill, c->d_sphere_geom, c->d_pair_parent,
+                    c->d_pair_parent32, c->d_spheres, c->d_triangles, c->d_materials};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    c->d_shade_rec = nullptr; c->d_nodes = nullptr; c->d_nodes4 = nullptr; c->d_nodes_ch = nullptr; c->d_stack_spill = nullptr;
+    c->d_sphere_geom = nullptr; c->d_pair_parent = nullptr; c->d_pair_parent32 = nullptr; c->d_spheres = nullptr; c->d_triangles = nullptr;
+    c->d_materials = nullptr;
+    c->scene = SceneDev{};
+    c->ch_ok = false;
+}
+
+// Uploads the scene in the reference's layouts (pt:120-128) plus the traversal's derivatives of it: primitive geometry,
+// the sibling-pair parent table, per-primitive shade records, conservative boxes (LDS-resident scenes) or four-wide nodes
+// (scenes beyond LDS), and sizes the launches for it. `pair_parent` / `bvh_depth` come from validate_bvh.
+int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *triangles, uint32_t n_spheres, const wfpt_material *materials,
+                 uint32_t n_materials, const wfpt_bvh_node *nodes, uint32_t n_nodes, const std::vector<uint32_t> &pair_parent,
+                 uint32_t bvh_depth, const wfpt_gpu_camera *camera) {
+    free_scene(c);
+    const uint32_t prim_kind = triangles ? 1u : 0u;
+    c->h_prim_mat_type.resize(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; ++i)
+        c->h_prim_mat_type[i] = spheres ? spheres[i].material_type : triangles[i].material_type;
+    WFPT_HIP(c, dmalloc(&c->d_nodes, n_nodes));
+    WFPT_HIP(c, dmalloc(&c->d_materials, n_materials));
+    WFPT_HIP(c, hipMemcpy(c->d_nodes, nodes, sizeof(wfpt_bvh_node) * n_nodes, hipMemcpyHostToDevice));
+    WFPT_HIP(c, hipMemcpy(c->d_materials, materials, sizeof(wfpt_material) * n_materials, hipMemcpyHostToDevice));
+    if (spheres) {
+        std::vector<float4> geom(n_spheres);
+        for (uint32_t i = 0; i < n_spheres; ++i)
+            geom[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
+        WFPT_HIP(c, dmalloc(&c->d_sphere_geom, n_spheres));
+        WFPT_HIP(c, dmalloc(&c->d_spheres, n_spheres));
+        WFPT_HIP(c, hipMemcpy(c->d_sphere_geom, geom.data(), sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
+        WFPT_HIP(c, hipMemcpy(c->d_spheres, spheres, sizeof(wfpt_sphere) * n_spheres, hipMemcpyHostToDevice));
+        c->scene.prim_geom = c->d_sphere_geom;
+    } else {
+        WFPT_HIP(c, dmalloc(&c->d_triangles, n_spheres));
+        WFPT_HIP(c, hipMemcpy(c->d_triangles, triangles, sizeof(wfpt_triangle) * n_spheres, hipMemcpyHostToDevice));
+        c->scene.prim_geom = reinterpret_cast<const float4 *>(c->d_triangles); // 3 x float4 per triangle
+    }
+    // per-primitive shade records (sphere / triangle fields merged with the material they point at)
+    {
+        std::vector<ShadeRec> recs(n_spheres);
+        for (uint32_t i = 0; i < n_spheres; ++i) {
+            ShadeRec &r = recs[i];
+            const wfpt_material &m = materials[spheres ? spheres[i].material_idx : triangles[i].material_idx];
+            if (spheres) {
+                r.v[0] = spheres[i].center[0]; r.v[1] = spheres[i].center[1]; r.v[2] = spheres[i].center[2];
+            } else { // normalize(cross(e1, e2)): fixed operation order, true divisions, no contraction (-ffp-contract=off)
+                const float *e1 = triangles[i].e1, *e2 = triangles[i].e2;
+                const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                const float len = std::sqrt((nx * nx + ny * ny) + nz * nz);
+                r.v[0] = nx / len; r.v[1] = ny / len; r.v[2] = nz / len;
+            }
+            r.fuzz = m.fuzz;
+            r.albedo[0] = m.albedo[0]; r.albedo[1] = m.albedo[1]; r.albedo[2] = m.albedo[2];
+            r.refract_index = m.refract_index;
+            r.mat_type = c->h_prim_mat_type[i]; // sphere.material_type, which extend copies into the payload (ex:199)
+            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+        }
+        static_assert(sizeof(ShadeRec) == 48, "ShadeRec is read as three float4");
+        WFPT_HIP(c, dmalloc(&c->d_shade_rec, 3 * static_cast<size_t>(n_spheres)));
+        WFPT_HIP(c, hipMemcpy(c->d_shade_rec, recs.data(), sizeof(ShadeRec) * n_spheres, hipMemcpyHostToDevice));
+        c->scene.shade_rec = c->d_shade_rec;
+    }
+    // LDS variant when nodes + primitives + parents fit comfortably (>= 2 workgroups per CU); otherwise the
+    // scene stays in HBM / Infinity Cache and extend reads it through L2.
+    const uint32_t lds_need = extend_lds_bytes(n_nodes, n_spheres, prim_kind, true);
+    const bool lds_scene = n_nodes <= 65536u && lds_need <= 80u * 1024u && !(c->p.flags & WFPT_FLAG_NO_LDS_SCENE);
+    const bool flag_exact = (c->p.flags & WFPT_FLAG_EXACT_TRAVERSAL) != 0;
+    float reach[3];
+    camera_reach(*camera, reach);
+    if (lds_scene) {
+        std::vector<uint16_t> p16(pair_parent.begin(), pair_parent.end());
+        WFPT_HIP(c, dmalloc(&c->d_pair_parent, p16.size()));
+        WFPT_HIP(c, hipMemcpy(c->d_pair_parent, p16.data(), sizeof(uint16_t) * p16.size(), hipMemcpyHostToDevice));
+        std::vector<float4> ch;
+        if (build_nodes_ch(nodes, n_nodes, reach, ch, c->extent)) {
+            WFPT_HIP(c, dmalloc(&c->d_nodes_ch, ch.size()));
+            WFPT_HIP(c, hipMemcpy(c->d_nodes_ch, ch.data(), sizeof(float4) * ch.size(), hipMemcpyHostToDevice));
+            c->scene.nodes_ch = c->d_nodes_ch;
+            c->ch_ok = true;
+        }
+    } else {
+        WFPT_HIP(c, dmalloc(&c->d_pair_parent32, pair_parent.size()));
+        WFPT_HIP(c, hipMemcpy(c->d_pair_parent32, pair_parent.data(), sizeof(uint32_t) * pair_parent.size(), hipMemcpyHostToDevice));
+    }
+    // four-wide nodes for the HBM-resident traversal (not the reference's walk: WFPT_FLAG_EXACT_TRAVERSAL keeps the binary tree)
+    if (!lds_scene && !(c->p.flags & WFPT_FLAG_BINARY_BVH) && !flag_exact) {
+        std::vector<Node4> n4;
+        if (collapse_bvh4(nodes, n_nodes, n4, c->depth4)) {
+            WFPT_HIP(c, dmalloc(&c->d_nodes4, 4 * n4.size()));
+            WFPT_HIP(c, hipMemcpy(c->d_nodes4, n4.data(), sizeof(Node4) * n4.size(), hipMemcpyHostToDevice));
+            c->scene.nodes4 = c->d_nodes4;
+        }
+    }
+    const bool want_dense = c->fused && c->scene.nodes4 && !(c->p.flags & WFPT_FLAG_NO_REFILL);
+    if (want_dense && !c->rec_dense) WFPT_HIP(c, dmalloc(&c->rec_dense, 2 * static_cast<size_t>(c->batch_max) * c->capacity));
+    if (!want_dense && c->rec_dense) {
+        (void)hipFree(c->rec_dense);
+        c->rec_dense = nullptr;
+    }
+    c->scene.nodes = c->d_nodes;
+    c->scene.pair_parent = c->d_pair_parent;
+    c->scene.pair_parent32 = c->d_pair_parent32;
+    c->scene.spheres = c->d_spheres;
+    c->scene.triangles = c->d_triangles;
+    c->scene.materials = c->d_materials;
+    c->scene.n_nodes = n_nodes;
+    c->scene.n_spheres = n_spheres;
+    c->scene.n_materials = n_materials;
+    c->scene.prim_kind = prim_kind;
+    c->scene.lds_scene = lds_scene ? 1u : 0u;
+    c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres, prim_kind, lds_scene);
+    c->scene.depth = bvh_depth;
+    c->far_rays = false;
+    decide_exact(c, reach);
+
+    int blocks_per_cu = 1;
+    WFPT_HIP(c, extend_blocks_per_cu(c->scene, &blocks_per_cu));
+    c->blocks_per_cu = static_cast<uint32_t>(std::max(blocks_per_cu, 1));
+    int bounce_blocks = 1;
+    WFPT_HIP(c, bounce_blocks_per_cu(c->scene, &bounce_blocks));
+    c->bounce_blocks_per_cu = static_cast<uint32_t>(std::max(bounce_blocks, 1));
+    if (c->scene.nodes4) { // spill area of the four-wide traversal's stack: at most 3 pushes per level
+        const uint32_t need = 3u * (c->depth4 + 1u);
+        const uint32_t spill_entries = need > kStack4Lds ? need - kStack4Lds : 1u;
+        c->scene.spill_stride = c->cus * std::max(c->blocks_per_cu, c->bounce_blocks_per_cu) * static_cast<uint32_t>(kExtendThreads);
+        WFPT_HIP(c, dmalloc(&c->d_stack_spill, static_cast<size_t>(spill_entries) * c->scene.spill_stride));
+        c->scene.stack_spill = c->d_stack_spill;
+    }
+    return WFPT_OK;
+}
+
 // Rebuilds the reference-order queue from the segment-compacted one: segment c's entries go to
 // positions [base[c], base[c] + count[c]).
 template <typename Emit>
@@ -582,6 +785,8 @@ int walk_segments(wfpt_ctx *c, bool hits, uint32_t n, Emit emit) {
 } // namespace
 
 extern "C" {
+
+static int alloc_gather_buffers(wfpt_ctx *c); // with the RCCL gather, below
 
 const char *wfpt_build_info(void) {
     static const std::string info = std::string("arch=gfx950;chunk=") + std::to_string(kChunk) +
@@ -693,9 +898,10 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(dmalloc(&c->mat_list, 3 * nb * c->capacity));
     CREATE_HIP(dmalloc(&c->chunk_mat, 3 * n_counts));
     CREATE_HIP(hipMemsetAsync(c->chunk_mat, 0, sizeof(uint32_t) * 3 * n_counts, c->stream));
-    c->image_floats = (3 * static_cast<size_t>(c->pixel_capacity) + 7) / 4 * 4; // slices stay 16-byte aligned
+    c->image_floats = 4 * static_cast<size_t>(c->pixel_capacity); // one float4 per pixel (kernels: pixel_of)
+    c->acc_floats = (3 * static_cast<size_t>(c->pixel_capacity) + 7) / 4 * 4;
     CREATE_HIP(dmalloc(&c->image, nb_all * c->image_floats));
-    CREATE_HIP(dmalloc(&c->accumulated, c->image_floats));
+    CREATE_HIP(dmalloc(&c->accumulated, c->acc_floats));
     CREATE_HIP(launch_fill(c->image, 1.0f, nb_all * c->image_floats, c->stream));                        // pt:53-58
     if (c->fused) {
         const size_t slots = nb_all * c->capacity, counts = nb_all * c->n_chunks_max;
@@ -711,94 +917,23 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         CREATE_HIP(dmalloc(&c->first_seg, counts));
         CREATE_HIP(hipMemsetAsync(c->first_seg, 0, sizeof(uint32_t) * counts, c->stream));
     }
-    CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->image_floats, c->stream));       // pt:60-65
+    CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->acc_floats, c->stream));         // pt:60-65
     CREATE_HIP(dmalloc(&c->ctl, kMaxBatch));
     CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control) * kMaxBatch, c->stream));
     CREATE_HIP(dmalloc(&c->camera, 1));
 
-    // scene upload (pt:120-128) plus the traversal's copies: primitive geometry and the sibling-pair parent table
-    const uint32_t prim_kind = triangles ? 1u : 0u;
-    c->h_prim_mat_type.resize(n_spheres);
-    for (uint32_t i = 0; i < n_spheres; ++i)
-        c->h_prim_mat_type[i] = spheres ? spheres[i].material_type : triangles[i].material_type;
-    CREATE_HIP(dmalloc(&c->d_nodes, n_nodes));
-    CREATE_HIP(dmalloc(&c->d_materials, n_materials));
-    CREATE_HIP(hipMemcpy(c->d_nodes, nodes, sizeof(wfpt_bvh_node) * n_nodes, hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(c->d_materials, materials, sizeof(wfpt_material) * n_materials, hipMemcpyHostToDevice));
-    if (spheres) {
-        std::vector<float4> geom(n_spheres);
-        for (uint32_t i = 0; i < n_spheres; ++i)
-            geom[i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
-        CREATE_HIP(dmalloc(&c->d_sphere_geom, n_spheres));
-        CREATE_HIP(dmalloc(&c->d_spheres, n_spheres));
-        CREATE_HIP(hipMemcpy(c->d_sphere_geom, geom.data(), sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
-        CREATE_HIP(hipMemcpy(c->d_spheres, spheres, sizeof(wfpt_sphere) * n_spheres, hipMemcpyHostToDevice));
-        c->scene.prim_geom = c->d_sphere_geom;
-    } else {
-        CREATE_HIP(dmalloc(&c->d_triangles, n_spheres));
-        CREATE_HIP(hipMemcpy(c->d_triangles, triangles, sizeof(wfpt_triangle) * n_spheres, hipMemcpyHostToDevice));
-        c->scene.prim_geom = reinterpret_cast<const float4 *>(c->d_triangles); // 3 x float4 per triangle
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->cus = static_cast<uint32_t>(prop.multiProcessorCount);
+    const uint32_t cus = c->cus;
+    // scene upload (pt:120-128) plus the traversal's own copies of it
+    c->h_camera = *camera;
+    if (upload_scene(c, spheres, triangles, n_spheres, materials, n_materials, nodes, n_nodes, pair_parent, static_cast<uint32_t>(bvh_depth),
+                     camera) != WFPT_OK) {
+        g_last_error = c->err;
+        wfpt_destroy(c);
+        return nullptr;
     }
-    // per-primitive shade records (sphere / triangle fields merged with the material they point at)
-    {
-        std::vector<ShadeRec> recs(n_spheres);
-        for (uint32_t i = 0; i < n_spheres; ++i) {
-            ShadeRec &r = recs[i];
-            const wfpt_material &m = materials[spheres ? spheres[i].material_idx : triangles[i].material_idx];
-            if (spheres) {
-                r.v[0] = spheres[i].center[0]; r.v[1] = spheres[i].center[1]; r.v[2] = spheres[i].center[2];
-            } else { // normalize(cross(e1, e2)): fixed operation order, true divisions, no contraction (-ffp-contract=off)
-                const float *e1 = triangles[i].e1, *e2 = triangles[i].e2;
-                const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-                const float len = std::sqrt((nx * nx + ny * ny) + nz * nz);
-                r.v[0] = nx / len; r.v[1] = ny / len; r.v[2] = nz / len;
-            }
-            r.fuzz = m.fuzz;
-            r.albedo[0] = m.albedo[0]; r.albedo[1] = m.albedo[1]; r.albedo[2] = m.albedo[2];
-            r.refract_index = m.refract_index;
-            r.mat_type = c->h_prim_mat_type[i]; // sphere.material_type, which extend copies into the payload (ex:199)
-            r._pad[0] = r._pad[1] = r._pad[2] = 0;
-        }
-        static_assert(sizeof(ShadeRec) == 48, "ShadeRec is read as three float4");
-        CREATE_HIP(dmalloc(&c->d_shade_rec, 3 * static_cast<size_t>(n_spheres)));
-        CREATE_HIP(hipMemcpy(c->d_shade_rec, recs.data(), sizeof(ShadeRec) * n_spheres, hipMemcpyHostToDevice));
-        c->scene.shade_rec = c->d_shade_rec;
-    }
-    // LDS variant when nodes + primitives + parents fit comfortably (>= 2 workgroups per CU); otherwise the
-    // scene stays in HBM / Infinity Cache and extend reads it through L2.
-    const uint32_t lds_need = extend_lds_bytes(n_nodes, n_spheres, prim_kind, true);
-    const bool lds_scene = n_nodes <= 65536u && lds_need <= 80u * 1024u && !(params->flags & WFPT_FLAG_NO_LDS_SCENE);
-    if (lds_scene) {
-        std::vector<uint16_t> p16(pair_parent.begin(), pair_parent.end());
-        CREATE_HIP(dmalloc(&c->d_pair_parent, p16.size()));
-        CREATE_HIP(hipMemcpy(c->d_pair_parent, p16.data(), sizeof(uint16_t) * p16.size(), hipMemcpyHostToDevice));
-    } else {
-        CREATE_HIP(dmalloc(&c->d_pair_parent32, pair_parent.size()));
-        CREATE_HIP(hipMemcpy(c->d_pair_parent32, pair_parent.data(), sizeof(uint32_t) * pair_parent.size(), hipMemcpyHostToDevice));
-    }
-    if (!lds_scene && !(params->flags & WFPT_FLAG_BINARY_BVH)) { // four-wide nodes for the HBM-resident traversal
-        std::vector<Node4> n4;
-        if (collapse_bvh4(nodes, n_nodes, n4, c->depth4)) {
-            CREATE_HIP(dmalloc(&c->d_nodes4, 4 * n4.size()));
-            CREATE_HIP(hipMemcpy(c->d_nodes4, n4.data(), sizeof(Node4) * n4.size(), hipMemcpyHostToDevice));
-            c->scene.nodes4 = c->d_nodes4;
-        }
-    }
-    if (c->fused && c->scene.nodes4 && !(params->flags & WFPT_FLAG_NO_REFILL))
-        CREATE_HIP(dmalloc(&c->rec_dense, 2 * nb_all * c->capacity));
-    c->scene.nodes = c->d_nodes;
-    c->scene.pair_parent = c->d_pair_parent;
-    c->scene.pair_parent32 = c->d_pair_parent32;
-    c->scene.spheres = c->d_spheres;
-    c->scene.triangles = c->d_triangles;
-    c->scene.materials = c->d_materials;
-    c->scene.n_nodes = n_nodes;
-    c->scene.n_spheres = n_spheres;
-    c->scene.n_materials = n_materials;
-    c->scene.prim_kind = prim_kind;
-    c->scene.lds_scene = lds_scene ? 1u : 0u;
-    c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres, prim_kind, lds_scene);
-    c->scene.depth = static_cast<uint32_t>(bvh_depth);
 
     CameraDev cam{};
     cam.cam = *camera;
@@ -808,25 +943,7 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     const wfpt_frame_buffer f{c->width, c->height, 0u, 0u};
     CREATE_HIP(hipMemcpy(&c->ctl->frame, &f, sizeof f, hipMemcpyHostToDevice));
 
-    hipDeviceProp_t prop;
-    CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
-    int blocks_per_cu = 1;
-    CREATE_HIP(extend_blocks_per_cu(c->scene, &blocks_per_cu));
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    const uint32_t cus = static_cast<uint32_t>(prop.multiProcessorCount);
-    c->cus = cus;
-    c->blocks_per_cu = static_cast<uint32_t>(blocks_per_cu);
-    int bounce_blocks = 1;
-    CREATE_HIP(bounce_blocks_per_cu(c->scene, &bounce_blocks));
-    c->bounce_blocks_per_cu = static_cast<uint32_t>(std::max(bounce_blocks, 1));
-    if (c->scene.nodes4) { // spill area of the four-wide traversal's stack: at most 3 pushes per level
-        const uint32_t need = 3u * (c->depth4 + 1u);
-        const uint32_t spill_entries = need > kStack4Lds ? need - kStack4Lds : 1u;
-        c->scene.spill_stride = cus * std::max(c->blocks_per_cu, c->bounce_blocks_per_cu) * static_cast<uint32_t>(kExtendThreads);
-        CREATE_HIP(dmalloc(&c->d_stack_spill, static_cast<size_t>(spill_entries) * c->scene.spill_stride));
-        c->scene.stack_spill = c->d_stack_spill;
-    }
-    c->accumulate_grid = std::min<uint32_t>((3u * c->pixel_capacity / 4u + 255u) / 256u, cus * 8u);
+    c->accumulate_grid = std::min<uint32_t>((c->pixel_capacity / 4u + 255u) / 256u, cus * 8u); // one thread per 4 pixels
     if (c->accumulate_grid == 0) c->accumulate_grid = 1;
     CREATE_HIP(hipStreamSynchronize(c->stream));
 #undef CREATE_HIP
@@ -874,8 +991,10 @@ static int render_chunked_impl(const wfpt_params *params, const wfpt_sphere *sph
         p.tile_rank = k;
         p.tile_world = chunks;
         p.max_pixels = 0;
+        if (bands_of(h, k, chunks) == 0) continue; // more chunks than bands: nothing to render for this one
+        g_last_status = WFPT_ERR_HIP;
         wfpt_ctx *c = create_impl(&p, spheres, triangles, n_prims, materials, n_materials, nodes, n_nodes, camera, inv_proj, view);
-        if (!c) return WFPT_ERR_HIP; // wfpt_last_error(NULL) holds the reason
+        if (!c) return g_last_status; // the status create_impl failed with; wfpt_last_error(NULL) holds the reason
         int r = wfpt_render(c, n_samples);
         if (r == WFPT_OK) {
             slab.resize(3 * static_cast<size_t>(c->n_pixels));
@@ -921,13 +1040,12 @@ void wfpt_destroy(wfpt_ctx *c) {
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
+    free_scene(c);
     void *bufs[] = {c->rec_dense, c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
                     c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg,
-                    c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->d_shade_rec, c->chunk_hits,
+                    c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
-                    c->camera,
-                    c->d_nodes, c->d_nodes4, c->d_stack_spill, c->d_sphere_geom, c->d_pair_parent, c->d_pair_parent32, c->d_spheres, c->d_triangles,
-                    c->d_materials};
+                    c->camera};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -961,12 +1079,57 @@ int wfpt_update_render_parameters(wfpt_ctx *c, uint32_t width, uint32_t height, 
     std::memcpy(cam.inv_proj, inv_proj, sizeof cam.inv_proj);
     std::memcpy(cam.view, view, sizeof cam.view);
     WFPT_HIP(c, hipMemcpy(c->camera, &cam, sizeof cam, hipMemcpyHostToDevice));       // pt:259-272
-    WFPT_HIP(c, hipMemsetAsync(c->accumulated, 0, sizeof(float) * 3 * static_cast<size_t>(c->pixel_capacity), c->stream)); // pt:248-250
+    WFPT_HIP(c, hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->acc_floats, c->stream)); // pt:248-250
     c->progress_frame = 0;      // RenderProgress::reset, pt:276
     c->accumulated_samples = 0;
     c->dev_frame_valid = false;
-    destroy_graph(c); // grid shapes are baked into the captured graph
-    return WFPT_OK;
+    destroy_graph(c); // grid shapes (and the kernel variant) are baked into the captured graph
+    c->h_camera = *camera;
+    float reach[3];
+    camera_reach(*camera, reach);
+    decide_exact(c, reach); // a camera far outside the scene leaves the conservative box test's error bound
+    return alloc_gather_buffers(c);
+}
+
+// Dynamic scenes: the scene of a live context is replaced in place. The BVH is rebuilt on the
+// context's device by the device builder (byte-identical to bvh.rs:147-210, so the oracle chain stays the checker), the
+// traversal's derived data (shade records, conservative boxes or four-wide nodes, parent table) re-derived, and the
+// accumulation reset as update_buffers does for a parameter change (pt:240-277): the next sample is frame 1 again.
+static int update_scene_impl(wfpt_ctx *c, wfpt_sphere *spheres, wfpt_triangle *triangles, uint32_t n_prims, const wfpt_material *materials,
+                             uint32_t n_materials, uint32_t n_bins) {
+    if (!c || !(spheres || triangles) || !materials || n_prims == 0 || n_materials == 0)
+        return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_scene: null or empty argument");
+    for (uint32_t i = 0; i < n_prims; ++i)
+        if ((spheres ? spheres[i].material_idx : triangles[i].material_idx) >= n_materials)
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_scene: primitive material_idx out of range");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still read the old scene
+    std::vector<wfpt_bvh_node> nodes(2 * static_cast<size_t>(n_prims));
+    uint32_t n_nodes = 0;
+    const int st = spheres ? wfpt_build_bvh_device(spheres, n_prims, nodes.data(), static_cast<uint32_t>(nodes.size()), &n_nodes, c->device, nullptr)
+                           : wfpt_build_bvh_triangles_device(triangles, n_prims, nodes.data(), static_cast<uint32_t>(nodes.size()), &n_nodes,
+                                                             n_bins ? n_bins : 32u, c->device, nullptr);
+    if (st != WFPT_OK) return fail(c, st, std::string("wfpt_update_scene: BVH build failed: ") + g_last_error);
+    std::vector<uint32_t> pair_parent;
+    const int depth = validate_bvh(c, nodes.data(), n_nodes, n_prims, pair_parent);
+    if (depth < 0) return depth;
+    destroy_graph(c); // scene pointers and launch shapes are baked into the captured graphs
+    if (int r = upload_scene(c, spheres, triangles, n_prims, materials, n_materials, nodes.data(), n_nodes, pair_parent,
+                             static_cast<uint32_t>(depth), &c->h_camera);
+        r != WFPT_OK)
+        return r;
+    return wfpt_reset_progress(c);
+}
+
+int wfpt_update_scene(wfpt_ctx *c, wfpt_sphere *spheres, uint32_t n_spheres, const wfpt_material *materials, uint32_t n_materials) {
+    if (!spheres) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_scene: null argument");
+    return update_scene_impl(c, spheres, nullptr, n_spheres, materials, n_materials, 0);
+}
+
+int wfpt_update_scene_mesh(wfpt_ctx *c, wfpt_triangle *triangles, uint32_t n_triangles, const wfpt_material *materials, uint32_t n_materials,
+                           uint32_t n_bins) {
+    if (!triangles) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_scene_mesh: null argument");
+    return update_scene_impl(c, nullptr, triangles, n_triangles, materials, n_materials, n_bins);
 }
 
 int wfpt_set_counters(wfpt_ctx *c, const uint32_t counters[16]) {
@@ -1164,7 +1327,11 @@ int wfpt_read_image(wfpt_ctx *c, float *rgb, size_t n_floats) {
     if (n_floats > 3 * static_cast<size_t>(c->n_pixels)) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "n_floats exceeds the image");
     WFPT_HIP(c, hipSetDevice(c->device));
     WFPT_HIP(c, hipStreamSynchronize(c->stream));
-    WFPT_HIP(c, hipMemcpy(rgb, c->image, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+    // the device keeps one float4 per pixel; the reference layout (stride 12, sh:6-10) is what crosses the ABI
+    const size_t n_px = (n_floats + 2) / 3;
+    std::vector<float> tmp(4 * n_px);
+    WFPT_HIP(c, hipMemcpy(tmp.data(), c->image, sizeof(float) * tmp.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n_floats; ++i) rgb[i] = tmp[4 * (i / 3) + i % 3];
     return WFPT_OK;
 }
 
@@ -1209,6 +1376,14 @@ int wfpt_write_rays(wfpt_ctx *c, const wfpt_ray *rays, uint32_t n) {
         bool ok = px < c->pixel_capacity;
         if (c->tile.world > 1) ok = px < c->width * c->height && ((px / c->width) >> 3) % c->tile.world == c->tile.rank;
         if (!ok) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: pixel_idx outside the image this context holds");
+        // an origin beyond the range the conservative box test's margin was sized for (or not a number): the stage API's
+        // extend switches to the reference's own box test for this context
+        for (int ax = 0; ax < 3 && c->ch_ok && !c->far_rays; ++ax)
+            if (!(std::fabs(rays[i].origin[ax]) <= 4.0f * c->extent[ax])) c->far_rays = true;
+    }
+    if (c->far_rays && !c->scene.exact) {
+        c->scene.exact = 1u;
+        destroy_graph(c);
     }
     WFPT_HIP(c, hipSetDevice(c->device));
     wfpt_ray *tmp = nullptr;
@@ -1342,6 +1517,33 @@ int rccl_fail(wfpt_ctx *c, ncclResult_t r, const char *what) {
 
 } // namespace
 
+// Root side of the gather: the assembled frame (whole bands) and the staging area the peers' slabs land in, sized for the
+// CURRENT viewport. Called by wfpt_comm_init and again by wfpt_update_render_parameters: a wider, shorter viewport of the same
+// pixel count needs more whole-band floats than the one the communicator was created with.
+static int alloc_gather_buffers(wfpt_ctx *c) {
+    if (!c->comm || c->comm_rank != 0) return WFPT_OK;
+    const size_t band_floats = 8u * static_cast<size_t>(c->width) * 3u;
+    const size_t frame_floats = static_cast<size_t>((c->height + 7u) / 8u) * band_floats;
+    size_t stage_floats = 0;
+    for (int r = 1; r < c->comm_world; ++r)
+        stage_floats += bands_of(c->height, static_cast<uint32_t>(r), static_cast<uint32_t>(c->comm_world)) * band_floats;
+    if (frame_floats > c->gather_frame_floats || !c->gather_frame) {
+        if (c->gather_frame) (void)hipFree(c->gather_frame);
+        c->gather_frame = nullptr;
+        c->gather_frame_floats = 0;
+        WFPT_HIP(c, dmalloc(&c->gather_frame, frame_floats));
+        c->gather_frame_floats = frame_floats;
+    }
+    if (stage_floats > c->gather_stage_floats || !c->gather_stage) {
+        if (c->gather_stage) (void)hipFree(c->gather_stage);
+        c->gather_stage = nullptr;
+        c->gather_stage_floats = 0;
+        WFPT_HIP(c, dmalloc(&c->gather_stage, stage_floats));
+        c->gather_stage_floats = stage_floats;
+    }
+    return WFPT_OK;
+}
+
 int wfpt_comm_unique_id(void *id128) {
     if (!id128) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_comm_unique_id: null argument");
     if (!rccl().error.empty()) return fail(nullptr, WFPT_ERR_UNSUPPORTED, rccl().error);
@@ -1364,15 +1566,7 @@ int wfpt_comm_init(wfpt_ctx *c, const void *id128, int rank, int world) {
     WFPT_RCCL(c, rccl().CommInitRank(&c->comm, world, id, rank)); // collective: every rank of the job calls it
     c->comm_rank = rank;
     c->comm_world = world;
-    if (rank == 0) { // the root assembles whole bands; peers' slabs land in a staging area first
-        const size_t band_floats = 8u * static_cast<size_t>(c->width) * 3u;
-        const size_t n_bands = (c->height + 7u) / 8u;
-        WFPT_HIP(c, dmalloc(&c->gather_frame, n_bands * band_floats));
-        size_t stage = 0;
-        for (int r = 1; r < world; ++r) stage += bands_of(c->height, static_cast<uint32_t>(r), static_cast<uint32_t>(world)) * band_floats;
-        WFPT_HIP(c, dmalloc(&c->gather_stage, stage));
-    }
-    return WFPT_OK;
+    return alloc_gather_buffers(c); // the root assembles whole bands; peers' slabs land in a staging area first
 }
 
 int wfpt_comm_destroy(wfpt_ctx *c) {
@@ -1386,6 +1580,7 @@ int wfpt_comm_destroy(wfpt_ctx *c) {
     if (c->gather_stage) (void)hipFree(c->gather_stage);
     if (c->gather_frame) (void)hipFree(c->gather_frame);
     c->gather_stage = c->gather_frame = nullptr;
+    c->gather_stage_floats = c->gather_frame_floats = 0;
     return WFPT_OK;
 }
 
@@ -1401,8 +1596,15 @@ int wfpt_gather_accumulated(wfpt_ctx *c) {
     const size_t band_floats = 8u * static_cast<size_t>(c->width) * 3u;
     if (rank != 0) {
         const size_t count = bands_of(c->height, rank, world) * band_floats;
+        if (count > c->acc_floats) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_gather_accumulated: the slab exceeds the accumulation buffer");
         if (count) WFPT_RCCL(c, rccl().Send(c->accumulated, count, ncclFloat, 0, c->comm, c->stream));
         return WFPT_OK;
+    }
+    {
+        size_t stage_need = 0;
+        for (uint32_t r = 1; r < world; ++r) stage_need += bands_of(c->height, r, world) * band_floats;
+        if (static_cast<size_t>((c->height + 7u) / 8u) * band_floats > c->gather_frame_floats || stage_need > c->gather_stage_floats)
+            return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_gather_accumulated: gather buffers are smaller than the current viewport needs");
     }
     if (world > 1) {
         WFPT_RCCL(c, rccl().GroupStart());

@@ -109,12 +109,16 @@ struct SceneDev {
     uint32_t lds_scene;           // 1: nodes + primitives + parents are staged in LDS by extend
     uint32_t lds_bytes;           // dynamic LDS the extend kernel needs for this scene
     uint32_t depth;               // levels below the root (validated <= kMaxTrailDepth)
-    // HBM-resident scenes: the binary tree collapsed into four-wide nodes (128 B each); null = walk
+    // HBM-resident scenes: the binary tree collapsed into four-wide nodes (64-byte quantised nodes); null = walk
     // the binary tree. Stack entries beyond the LDS column spill to `stack_spill`, entry k of global thread g at
     // [k * spill_stride + g].
     const float4 *nodes4;
     uint32_t *stack_spill;
     uint32_t spill_stride;
+    // LDS-resident scenes, default traversal: every node as (centre.xyz | left_first), (half-extent.xyz | prim_count), the
+    // half-extent grown by more than the box test's rounding error (trace_ray_conservative); staged instead of `nodes`
+    const float4 *nodes_ch;
+    uint32_t exact; // 1: WFPT_FLAG_EXACT_TRAVERSAL (or a fallback to it): the reference's box test and 1e30 miss value
 };
 
 constexpr uint32_t kStack4Lds = 16; // stack entries of the four-wide traversal kept in LDS (per lane)
@@ -138,7 +142,7 @@ struct Batch {
     size_t ray_stride;     // floats between ray-queue slices (7 * capacity)
     size_t queue_stride;   // elements between hit / miss queue slices (capacity)
     size_t chunk_stride;   // elements between per-segment count arrays
-    size_t image_stride;   // floats between image slices
+    size_t image_stride;   // floats between image slices (a slice holds one float4 per pixel)
 };
 
 struct GenerateArgs {
@@ -295,7 +299,7 @@ struct AccumulateArgs {
     const float *image;
     float *accumulated;
     Control *ctl;
-    uint32_t n_floats;
+    uint32_t n_pixels;
     uint32_t bookkeeping; // fused loop: fold the bounce table into totals, frame += 1
 };
 
@@ -311,6 +315,7 @@ hipError_t launch_shade(const ShadeArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s);
+hipError_t launch_set_frame(Control *ctl, const wfpt_frame_buffer &f, hipStream_t s); // ctl->frame = f, ordered on the stream
 // frame band (j * world + rank) <- slab band j for the first n_valid floats of a slab: the root of the multi-GPU gather
 hipError_t launch_band_scatter(float *frame, const float *slab, size_t n_valid, size_t band_floats, uint32_t world, uint32_t rank, hipStream_t s);
 // AoS <-> SoA converters for the read-back / injection paths

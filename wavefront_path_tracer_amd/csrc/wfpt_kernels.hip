@@ -35,6 +35,12 @@ __device__ __forceinline__ uint32_t local_pixel(uint32_t pixel, uint32_t width, 
 
 __device__ __forceinline__ RayQueue slice(RayQueue q, size_t off) { return {q.base + off, q.cap}; }
 
+// The per-sample throughput image (image_buffer, sh:6-10,47) keeps one float4 per pixel on the device, (r, g, b, unused): the
+// read-modify-write of shade / miss_kernel (sh:84-87, mk:35-37) is then ONE 16-byte load and ONE 16-byte store inside one
+// 64-byte line, where the reference's stride-12 layout costs three dword accesses that straddle lines for a quarter of the
+// pixels. The stride-12 layout is what crosses the C ABI (wfpt_read_image strips the pad; `accumulated` stays stride 12).
+__device__ __forceinline__ float4 *pixel_of(float *image, uint32_t local_px) { return reinterpret_cast<float4 *>(image) + local_px; }
+
 // WGSL mat4x4f * vec4f, m column-major: ((c0*x + c1*y) + c2*z) + c3*w per component
 struct float4_ { float x, y, z, w; };
 __device__ __forceinline__ float4_ mat_mul(const float *m, float4_ v) {
@@ -136,10 +142,7 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
     a.q.dx()[idx] = pr.dx; a.q.dy()[idx] = pr.dy; a.q.dz()[idx] = pr.dz;
     a.q.pixel()[idx] = pixel_idx;
     if (a.reset_image) { // pt:305-306 folded in: throughput starts at 1
-        const uint32_t lp = local_pixel(pixel_idx, width, a.tile);
-        a.image[3u * lp + 0u] = 1.0f;
-        a.image[3u * lp + 1u] = 1.0f;
-        a.image[3u * lp + 2u] = 1.0f;
+        *pixel_of(a.image, local_pixel(pixel_idx, width, a.tile)) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     }
 }
 
@@ -147,13 +150,15 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
 // extend (ex:47-210)
 // ================================================================================================
 // ex:164-183 with the node held as two float4 (min.xyz|left_first, max.xyz|prim_count).
-// A missed box reports kBoxMiss, a value ABOVE the reference's 1e30 (ex:181), which is also its "nothing hit yet" value of
-// `nearest`: while nothing is hit the reference's test `t_near > nearest` (ex:124) reads 1e30 > 1e30 = false for a pair
-// of boxes the ray misses both of, and it walks down into that pair, left child first, down to a leaf whose primitive
-// it then tests in vain (the primitive lies inside a box the ray misses). Those visits decide nothing; with the larger
-// miss value the same comparison leaves such a pair alone: 11 % fewer visits for primary rays, 7 % for the others
-// (oracle model, tools/model_schedule.py), the hits unchanged.
+// EXACT (WFPT_FLAG_EXACT_TRAVERSAL): a missed box reports the reference's 1e30 (ex:181). Otherwise it reports kBoxMiss,
+// a value ABOVE 1e30, which is also the reference's "nothing hit yet" value of `nearest`: while nothing is hit the
+// reference's test `t_near > nearest` (ex:124) reads 1e30 > 1e30 = false for a pair of boxes the ray misses both of,
+// and it walks down into that pair, left child first, down to a leaf whose primitive it then tests in vain (the
+// primitive lies inside a box the ray misses). Those visits decide nothing; with the larger miss value the same
+// comparison leaves such a pair alone: 11 % fewer visits for primary rays, 7 % for the others (oracle model,
+// tools/model_schedule.py), the hits unchanged.
 constexpr float kBoxMiss = 3.0e38f;
+template <bool EXACT>
 __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox, float oy, float oz, float ix,
                                               float iy, float iz, float nearest) {
     const float t_x_min = (bmin.x - ox) * ix;
@@ -168,38 +173,9 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
     const float t_z_max = (bmax.z - oz) * iz;
     tmin = max_(min_(t_z_min, t_z_max), tmin);
     tmax = min_(max_(t_z_min, t_z_max), tmax);
-    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? kBoxMiss : tmin;
+    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? (EXACT ? 1e30f : kBoxMiss) : tmin;
 }
 
-// The same test with each plane distance as ONE fused multiply-add, b * inv + (-(o * inv)): half the arithmetic of
-// (b - o) * inv. It is NOT the reference's rounding, so it is used only where a box test cannot change the result:
-// for spheres. The closest hit is the minimum over the spheres whose exact test (hit_prim) accepts, whatever boxes are
-// visited on the way; a box test only has to be conservative for the sphere it bounds. Both forms are within an ulp or
-// two of the true plane distances and can disagree only for rays that graze a box edge or corner within that error,
-// and a sphere touches its (and every enclosing) box at face centres only, a distance (sqrt(2) - 1) r away from the
-// nearest edge. Infinite inverses (axis-parallel rays) are clamped first, see trace_ray. Triangles reach the corners
-// of their boxes, so they keep the exact form.
-// Gate: every bit-exact test, and bench.py's comparison of the whole 64-spp full-HD frame with the oracle.
-__device__ __forceinline__ float hit_bvh_node_fma(float4 bmin, float4 bmax, float nox, float noy, float noz, float ix,
-                                                  float iy, float iz, float nearest) {
-    const float t_x_min = fma_(bmin.x, ix, nox);
-    const float t_x_max = fma_(bmax.x, ix, nox);
-    float tmin = min_(t_x_min, t_x_max);
-    float tmax = max_(t_x_min, t_x_max);
-    const float t_y_min = fma_(bmin.y, iy, noy);
-    const float t_y_max = fma_(bmax.y, iy, noy);
-    tmin = max_(min_(t_y_min, t_y_max), tmin);
-    tmax = min_(max_(t_y_min, t_y_max), tmax);
-    const float t_z_min = fma_(bmin.z, iz, noz);
-    const float t_z_max = fma_(bmax.z, iz, noz);
-    tmin = max_(min_(t_z_min, t_z_max), tmin);
-    tmax = min_(max_(t_z_min, t_z_max), tmax);
-    return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? kBoxMiss : tmin;
-}
-
-#ifndef WFPT_SLAB_FMA
-#define WFPT_SLAB_FMA 1 // spheres: one fma per box plane (see hit_bvh_node_fma)
-#endif
 #ifndef WFPT_BUDGET_INNER
 #define WFPT_BUDGET_INNER 0 // 1: count the step budget down on every inner visit as well (costs 3 instructions per visit)
 #endif
@@ -329,7 +305,7 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
     }
 }
 
-template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH>
+template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH, bool EXACT>
 __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *prim_geom, const ParentT *pair_parent,
                                           uint32_t *stack_column, float ox, float oy, float oz, float dx, float dy,
                                           float dz, uint32_t max_steps, float &t_out, uint32_t &prim_out) {
@@ -344,14 +320,6 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     tr.prim_count = __float_as_uint(nodes[1].w);
     tr.trail = 0;
     bool alive = true;
-    constexpr bool kFmaSlab = WFPT_SLAB_FMA != 0 && PRIM == 0;
-    // fused form: an infinite inverse (a direction component that is exactly zero, or denormal) would turn b * inv - o * inv
-    // into inf - inf for one plane of a slab and cull boxes the ray is inside of. Clamped to +-1e30 the two planes of an
-    // axis-parallel ray keep their signs (|b - o| * 1e30 stays finite for any sane scene) and the slab reads "always" or
-    // "never" exactly like the reference's +-inf. (A NaN inverse means a NaN direction: no sphere test can pass anyway.)
-    const float bx = kFmaSlab ? min_(max_(ix, -1e30f), 1e30f) : ix, by = kFmaSlab ? min_(max_(iy, -1e30f), 1e30f) : iy,
-                bz = kFmaSlab ? min_(max_(iz, -1e30f), 1e30f) : iz;
-    const float nox = kFmaSlab ? -(ox * bx) : ox, noy = kFmaSlab ? -(oy * by) : oy, noz = kFmaSlab ? -(oz * bz) : oz;
     // A traversal visits every node at most once, so `max_steps` (= node count) is never reached on a valid tree (the
     // tree is validated at wfpt_create: sibling layout, ranges, no cycles); the budget only guarantees that every wave
     // terminates if the node data were corrupt. It is counted per leaf / pop round; a descent between two leaves is at
@@ -364,10 +332,8 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
             const float4 *pair = nodes + 2u * tr.left_first;
             const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
             keep4(lmin, lmax, rmin, rmax);
-            const float t_left = kFmaSlab ? hit_bvh_node_fma(lmin, lmax, nox, noy, noz, bx, by, bz, nearest)
-                                          : hit_bvh_node(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
-            const float t_right = kFmaSlab ? hit_bvh_node_fma(rmin, rmax, nox, noy, noz, bx, by, bz, nearest)
-                                           : hit_bvh_node(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_left = hit_bvh_node<EXACT>(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_right = hit_bvh_node<EXACT>(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
             const bool swap = t_left > t_right; // strict: ties keep the left child first
             const float t_near = swap ? t_right : t_left;
             const float t_far = swap ? t_left : t_right;
@@ -388,6 +354,81 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
             for (uint32_t i = 0; i < tr.prim_count; ++i)
                 hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             alive = tr.pop(nodes, pair_parent);
+        }
+    }
+    t_out = nearest;
+    prim_out = best;
+    return nearest < 1e30f; // ex:157
+}
+
+// ---- the LDS-resident traversal as it runs by default: same walk, CONSERVATIVE box test ---------------------------
+// What `extend` reports is the minimum, over the primitives whose EXACT test (hit_prim, ex:185-210) accepts, of their t:
+// a box test only has to say "maybe" for every box the reference's test (ex:164-183) would enter. Here a box is kept as
+// centre c and half-extent h (SceneDev::nodes_ch, built at wfpt_create), h grown on the host by MORE than this test's
+// own rounding error can reach (conservative_margin(), wfpt_api.hip): for every ray whose origin lies within four scene
+// extents of the origin, computed entry distance <= the exact box's entry distance and computed exit distance >= its
+// exit distance. So every primitive the reference tests is tested here too, and the hits are the reference's by
+// construction, not by luck -- for spheres AND triangles (wfpt_create falls back to the exact test when a camera or an
+// injected ray lies outside that range, or when a box is not finite).
+//   per axis: tc = c * inv - o * inv (one fma against the per-ray constant -(o * inv)),
+//             t_entry = tc - h * |inv|, t_exit = tc + h * |inv| (one fma each; the sign of inv needs no min / max),
+//   entered  <=> max(t_entry over axes, 0) <= min(t_exit over axes, nearest)
+// 9 fma + max3 + min3 + max + min + compare per box where the reference form costs 6 sub/mul pairs + 12 min / max + 3
+// compares. The walk is the reference's (root box never tested; both children entered: nearer entry first, ties keep
+// the left child; the far one pending), with the two places where a conservative test is free to differ: a pair of
+// boxes the ray misses both of is left alone while nothing is hit yet (the reference's `1e30 > 1e30`, see kBoxMiss),
+// and a far child whose entry distance equals `nearest` exactly stays pending (the reference drops it at `<`; it cannot
+// hold a nearer hit). Infinite inverses (a direction component that is exactly zero) are clamped to +-1e30: the
+// two planes of such an axis then read "always" or "never" like the reference's +-inf, without inf - inf.
+template <typename Trail, int PRIM, typename ParentT>
+__device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
+                                                       float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
+                                                       uint32_t &prim_out) {
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float a = (dx * dx + dy * dy) + dz * dz; // dot(direction, direction), ex:190
+    const float bx = min_(max_(ix, -1e30f), 1e30f), by = min_(max_(iy, -1e30f), 1e30f), bz = min_(max_(iz, -1e30f), 1e30f);
+    const float nox = -(ox * bx), noy = -(oy * by), noz = -(oz * bz);
+    const float ax = __builtin_fabsf(bx), ay = __builtin_fabsf(by), az = __builtin_fabsf(bz);
+    float nearest = 1e30f;
+    uint32_t best = 0xffffffffu;
+    Traversal<Trail, ParentT, 0> tr;
+    tr.node = 0; // ex:84: the root's box is never tested
+    tr.left_first = __float_as_uint(nodes_ch[0].w);
+    tr.prim_count = __float_as_uint(nodes_ch[1].w);
+    tr.trail = 0;
+    bool alive = true;
+    uint32_t budget = max_steps; // see trace_ray
+    while (alive) {
+        while (alive && tr.prim_count == 0) {
+            if (WFPT_BUDGET_INNER && budget-- == 0) { alive = false; break; }
+            const float4 *pair = nodes_ch + 2u * tr.left_first;
+            const float4 lc = pair[0], lh = pair[1], rc = pair[2], rh = pair[3];
+            keep4(lc, lh, rc, rh);
+            const float lcx = fma_(lc.x, bx, nox), lcy = fma_(lc.y, by, noy), lcz = fma_(lc.z, bz, noz);
+            const float l_in = max_(max_(fma_(lh.x, -ax, lcx), fma_(lh.y, -ay, lcy)), fma_(lh.z, -az, lcz));
+            const float l_out = min_(min_(fma_(lh.x, ax, lcx), fma_(lh.y, ay, lcy)), fma_(lh.z, az, lcz));
+            const float rcx = fma_(rc.x, bx, nox), rcy = fma_(rc.y, by, noy), rcz = fma_(rc.z, bz, noz);
+            const float r_in = max_(max_(fma_(rh.x, -ax, rcx), fma_(rh.y, -ay, rcy)), fma_(rh.z, -az, rcz));
+            const float r_out = min_(min_(fma_(rh.x, ax, rcx), fma_(rh.y, ay, rcy)), fma_(rh.z, az, rcz));
+            const bool hit_l = max_(l_in, 0.0f) <= min_(l_out, nearest);
+            const bool hit_r = max_(r_in, 0.0f) <= min_(r_out, nearest);
+            const bool r_nearer = l_in > r_in;
+            const bool go_right = hit_r && (!hit_l || r_nearer); // nearer entry first; ties keep the left child (ex:119)
+            const bool both = hit_l && hit_r;
+            if (!(hit_l || hit_r)) {
+                alive = tr.pop(nodes_ch, pair_parent);
+            } else {
+                tr.node = tr.left_first + (go_right ? 1u : 0u);
+                tr.trail = (tr.trail << 1) | static_cast<Trail>(both ? 1u : 0u);
+                tr.left_first = __float_as_uint(go_right ? rc.w : lc.w);
+                tr.prim_count = __float_as_uint(go_right ? rh.w : lh.w);
+            }
+        }
+        if (alive && budget-- == 0) alive = false;
+        if (alive) { // leaf (ex:86-103)
+            for (uint32_t i = 0; i < tr.prim_count; ++i)
+                hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+            alive = tr.pop(nodes_ch, pair_parent);
         }
     }
     t_out = nearest;
@@ -449,7 +490,7 @@ __device__ __forceinline__ Visit4 visit4(const float4 *nodes4, uint32_t cur, flo
     for (int k = 0; k < 4; ++k) {
         const float4 lo = make_float4(fma_(ubyte(qlx, k), sx, a.x), fma_(ubyte(qly, k), sy, a.y), fma_(ubyte(qlz, k), sz, a.z), 0.0f);
         const float4 hi = make_float4(fma_(ubyte(qhx, k), sx, a.x), fma_(ubyte(qhy, k), sy, a.y), fma_(ubyte(qhz, k), sz, a.z), 0.0f);
-        t[k] = hit_bvh_node(lo, hi, ox, oy, oz, ix, iy, iz, nearest);
+        t[k] = hit_bvh_node<false>(lo, hi, ox, oy, oz, ix, iy, iz, nearest);
     }
     // a child is entered when the ray meets its box no farther than the nearest hit (hit_bvh_node returns 1e30 otherwise)
     v.t0 = (v.w0 == kEmptyChild || t[0] >= 1e30f) ? 2e30f : t[0];
@@ -506,7 +547,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
 // LDS exchange of the eight per-wave counts; no global atomics on queue slots (ex:59,61 use one per ray).
 // LDS_SCENE = false (build extension for scenes larger than a CU's LDS, e.g. BASELINE config 5's 1M-triangle
 // BVH): nodes, primitives and a 32-bit parent table are read from HBM / Infinity Cache through L2 instead.
-template <bool HAS_INACTIVE, typename Trail, int PRIM, bool LDS_SCENE>
+template <bool HAS_INACTIVE, typename Trail, int PRIM, bool LDS_SCENE, bool EXACT>
 #ifndef WFPT_EXTEND_MIN_WAVES
 #define WFPT_EXTEND_MIN_WAVES 8
 #endif
@@ -546,7 +587,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
     if (item >= n_items) return; // nothing to do: skip the LDS staging too
     const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
     if (LDS_SCENE) {
-        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_nodes[i];
+        const float4 *g_staged = EXACT ? g_nodes : a.scene.nodes_ch; // reference boxes, or conservative centre / half-extent boxes
+        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_staged[i];
         for (uint32_t i = threadIdx.x; i < geom_words; i += kExtendThreads) s_sphere[i] = a.scene.prim_geom[i];
         const uint4 *g_par = reinterpret_cast<const uint4 *>(a.scene.pair_parent);
         uint4 *s_par4 = reinterpret_cast<uint4 *>(s_parent);
@@ -578,19 +620,21 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         uint32_t prim = 0;
         bool hit = false;
         if (live) {
-            if (LDS_SCENE)
-                hit = trace_ray<Trail, PRIM, uint16_t, 0>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
-                                                          prim);
-            else if (a.scene.nodes4) {
+            if (LDS_SCENE && EXACT)
+                hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
+                                                                prim);
+            else if (LDS_SCENE)
+                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
                 st.lds = s_stack + threadIdx.x;
                 st.stride = a.scene.spill_stride;
                 st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
                 hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else
-                hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
-                                                                     s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
-                                                                     a.scene.n_nodes, t, prim);
+                hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
+                                                                            s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
+                                                                            a.scene.n_nodes, t, prim);
         }
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
@@ -917,9 +961,8 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             const float dx = a.q.dx()[ridx], dy = a.q.dy()[ridx], dz = a.q.dz()[ridx];
             const uint32_t pixel_idx = a.q.pixel()[ridx];
             // sh:84-87: throughput *= albedo, for every material type (load now, store after the scatter math)
-            const uint32_t lp = local_pixel(pixel_idx, a.image_width, a.tile);
-            float *px = a.image + 3u * static_cast<size_t>(lp);
-            const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
+            float4 *px = pixel_of(a.image, local_pixel(pixel_idx, a.image_width, a.tile));
+            const float4 thr = *px;
 
             const uint32_t rng = shade_rng(a.rng_mode, h, gx, pixel_idx, fb);
             // sh:91-93
@@ -929,9 +972,7 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
             a.ext.ox()[h] = p_x; a.ext.oy()[h] = p_y; a.ext.oz()[h] = p_z;
             a.ext.dx()[h] = ext.x; a.ext.dy()[h] = ext.y; a.ext.dz()[h] = ext.z;
             a.ext.pixel()[h] = pixel_idx;
-            px[0] = thr_r * rec1.x; // albedo
-            px[1] = thr_g * rec1.y;
-            px[2] = thr_b * rec1.z;
+            *px = make_float4(thr.x * rec1.x, thr.y * rec1.y, thr.z * rec1.z, thr.w); // albedo
         }
     }
 }
@@ -973,10 +1014,9 @@ __global__ __launch_bounds__(kConsumerThreads) void miss_kernel(MissArgs a) {
             const float cr = om * 1.0f + t * 0.5f; // mk:33
             const float cg = om * 1.0f + t * 0.7f;
             const float cb = om * 1.0f + t * 1.0f;
-            float *px = a.image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
-            px[0] *= cr; // mk:35-37
-            px[1] *= cg;
-            px[2] *= cb;
+            float4 *px = pixel_of(a.image, local_pixel(pixel_idx, a.image_width, a.tile));
+            const float4 thr = *px;
+            *px = make_float4(thr.x * cr, thr.y * cg, thr.z * cb, thr.w); // mk:35-37
         }
     }
 }
@@ -1011,8 +1051,8 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
     pixel_idx = __float_as_uint(ra.w);
     const uint32_t prim = __float_as_uint(rb.w);
     const float4 rec1 = s.shade_rec[3u * prim + 1u];
-    float *px = s.image + 3u * static_cast<size_t>(local_pixel(pixel_idx, s.image_width, s.tile));
-    const float thr_r = px[0], thr_g = px[1], thr_b = px[2];
+    float4 *px = pixel_of(s.image, local_pixel(pixel_idx, s.image_width, s.tile));
+    const float4 thr = *px;
     if (SCATTER) {
         const float4 rec0 = s.shade_rec[3u * prim], rec2 = s.shade_rec[3u * prim + 2u];
         const uint32_t rng = shade_rng(s.rng_mode, h, s.ctl->shade_gx, pixel_idx, fb);
@@ -1020,9 +1060,7 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
         ox = ra.x; oy = ra.y; oz = ra.z;
         dx = ext.x; dy = ext.y; dz = ext.z;
     }
-    px[0] = thr_r * rec1.x;
-    px[1] = thr_g * rec1.y;
-    px[2] = thr_b * rec1.z;
+    *px = make_float4(thr.x * rec1.x, thr.y * rec1.y, thr.z * rec1.z, thr.w);
 }
 
 // ================================================================================================
@@ -1057,7 +1095,7 @@ struct BounceLds {
 constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + 2u + kMaxBatch; // the two u16 tables take kMaxBatch words
 static_assert(kBounceMiscWords % 4u == 0, "the stack column area stays 16-byte aligned");
 
-template <int MODE, typename Trail, int PRIM, bool LDS_SCENE>
+template <int MODE, typename Trail, int PRIM, bool LDS_SCENE, bool EXACT>
 __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_kernel(BounceArgs a) {
     extern __shared__ float4 lds[];
     constexpr bool TRACE = MODE != kBounceLast;
@@ -1105,7 +1143,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     if (item >= n_items) return;
     const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
     if (stage_scene) {
-        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_nodes[i];
+        const float4 *g_staged = EXACT ? g_nodes : a.scene.nodes_ch; // reference boxes, or conservative centre / half-extent boxes
+        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_staged[i];
         for (uint32_t i = threadIdx.x; i < geom_words; i += kExtendThreads) s_geom[i] = a.scene.prim_geom[i];
         const uint4 *g_par = reinterpret_cast<const uint4 *>(a.scene.pair_parent);
         uint4 *s_par4 = reinterpret_cast<uint4 *>(s_parent);
@@ -1140,10 +1179,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                     const float cr = om * 1.0f + t * 0.5f; // mk:33
                     const float cg = om * 1.0f + t * 0.7f;
                     const float cb = om * 1.0f + t * 1.0f;
-                    float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, a.image_width, a.tile));
-                    px[0] *= cr; // mk:35-37
-                    px[1] *= cg;
-                    px[2] *= cb;
+                    float4 *px = pixel_of(image, local_pixel(pixel_idx, a.image_width, a.tile));
+                    const float4 thr = *px;
+                    *px = make_float4(thr.x * cr, thr.y * cg, thr.z * cb, thr.w); // mk:35-37
                 }
             }
             __syncthreads(); // L.next[buf] is visible
@@ -1175,8 +1213,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 pixel_idx = id_x + id_y * fb.width; // gr:57
                 const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
                 ox = pr.ox; oy = pr.oy; oz = pr.oz; dx = pr.dx; dy = pr.dy; dz = pr.dz;
-                float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, fb.width, a.tile));
-                px[0] = 1.0f; px[1] = 1.0f; px[2] = 1.0f; // pt:305-306 folded in: throughput starts at 1
+                *pixel_of(image, local_pixel(pixel_idx, fb.width, a.tile)) = make_float4(1.0f, 1.0f, 1.0f, 1.0f); // pt:305-306 folded in: throughput starts at 1
             }
         } else if (live) {
             // ---------------- shade (sh:56-156) of hit h of the previous wavefront
@@ -1195,17 +1232,19 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         uint32_t prim = 0;
         bool hit = false;
         if (live) {
-            if (LDS_SCENE)
-                hit = trace_ray<Trail, PRIM, uint16_t, 0>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
-            else if (a.scene.nodes4) {
+            if (LDS_SCENE && EXACT)
+                hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            else if (LDS_SCENE)
+                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
                 st.lds = L.stack + threadIdx.x;
                 st.stride = a.scene.spill_stride;
                 st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
                 hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else
-                hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
-                                                                     ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
+                                                                            ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
         }
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
@@ -1314,8 +1353,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                         pixel_idx = id_x + id_y * fb.width;
                         const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
                         ox = pr.ox; oy = pr.oy; oz = pr.oz; dx = pr.dx; dy = pr.dy; dz = pr.dz;
-                        float *px = image + 3u * static_cast<size_t>(local_pixel(pixel_idx, fb.width, a.tile));
-                        px[0] = 1.0f; px[1] = 1.0f; px[2] = 1.0f;
+                        *pixel_of(image, local_pixel(pixel_idx, fb.width, a.tile)) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                     } else { // a lane outside the image: neither hit nor miss
                         const size_t slot = smp * a.batch.queue_stride + ray;
                         a.dense_out[2u * slot + 1u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kDenseInactive));
@@ -1434,22 +1472,27 @@ __global__ __launch_bounds__(kExtendThreads) void compact_kernel(CompactArgs a) 
 // ================================================================================================
 __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
     // accumulated += image_0; += image_1; ... in sample order, so a batch gives exactly the sums that
-    // sequential samples (one accumulate dispatch each, pt:362) would.
-    const uint32_t n4 = a.n_floats / 4u;
+    // sequential samples (one accumulate dispatch each, pt:362) would. One thread = 4 pixels: 4 x 16 B of each image
+    // slice (float4 per pixel) in, 3 x 16 B of `accumulated` (the reference's stride-12 layout) read and written.
+    const uint32_t n_quads = a.n_pixels / 4u;
     float4 *acc4 = reinterpret_cast<float4 *>(a.accumulated);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        float4 s = acc4[i];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += gridDim.x * blockDim.x) {
+        float4 s0 = acc4[3u * i], s1 = acc4[3u * i + 1u], s2 = acc4[3u * i + 2u];
         for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-            const float4 v = reinterpret_cast<const float4 *>(a.image + smp * a.batch.image_stride)[i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            const float4 *im = reinterpret_cast<const float4 *>(a.image + smp * a.batch.image_stride) + 4u * static_cast<size_t>(i);
+            const float4 p0 = im[0], p1 = im[1], p2 = im[2], p3 = im[3];
+            s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p1.x;
+            s1.x += p1.y; s1.y += p1.z; s1.z += p2.x; s1.w += p2.y;
+            s2.x += p2.z; s2.y += p3.x; s2.z += p3.y; s2.w += p3.z;
         }
-        acc4[i] = s;
+        acc4[3u * i] = s0; acc4[3u * i + 1u] = s1; acc4[3u * i + 2u] = s2;
     }
     if (blockIdx.x == 0) {
-        const uint32_t tail = 4u * n4 + threadIdx.x;
-        if (tail < a.n_floats) {
+        const uint32_t tail = 12u * n_quads + threadIdx.x; // channels of the last n_pixels % 4 pixels
+        if (tail < 3u * a.n_pixels) {
+            const uint32_t px = tail / 3u, ch = tail - 3u * px;
             float s = a.accumulated[tail];
-            for (uint32_t smp = 0; smp < a.batch.n; ++smp) s += a.image[smp * a.batch.image_stride + tail];
+            for (uint32_t smp = 0; smp < a.batch.n; ++smp) s += a.image[smp * a.batch.image_stride + 4u * static_cast<size_t>(px) + ch];
             a.accumulated[tail] = s;
         }
         if (a.bookkeeping && threadIdx.x == 0) { // end of a fused batch
@@ -1478,6 +1521,9 @@ __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
 // ================================================================================================
 // helpers
 // ================================================================================================
+// the frame uniform of the next sample (pt:296-297), written on the stream: no host synchronisation between frames
+__global__ void set_frame_kernel(Control *ctl, wfpt_frame_buffer f) { ctl->frame = f; }
+
 __global__ void fill_kernel(float *p, float v, size_t n) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -1556,22 +1602,27 @@ uint32_t extend_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind
 
 namespace {
 using ExtendFn = void (*)(ExtendArgs);
-template <bool INACT, int PRIM> ExtendFn extend_pick(bool lds_scene, bool deep) {
-    if (!lds_scene) return extend_kernel<INACT, unsigned long long, PRIM, false>;
-    return deep ? extend_kernel<INACT, unsigned long long, PRIM, true> : extend_kernel<INACT, uint32_t, PRIM, true>;
+template <bool INACT, int PRIM, bool EXACT> ExtendFn extend_pick(bool lds_scene, bool deep) {
+    if (!lds_scene) return extend_kernel<INACT, unsigned long long, PRIM, false, EXACT>;
+    return deep ? extend_kernel<INACT, unsigned long long, PRIM, true, EXACT> : extend_kernel<INACT, uint32_t, PRIM, true, EXACT>;
+}
+template <bool EXACT> ExtendFn extend_variant_of(const SceneDev &sc, bool has_inactive) {
+    const bool lds = sc.lds_scene != 0, deep = sc.depth > 31u; // a 32-bit trail covers trees up to 31 levels deep
+    if (sc.prim_kind == 0) return has_inactive ? extend_pick<true, 0, EXACT>(lds, deep) : extend_pick<false, 0, EXACT>(lds, deep);
+    return has_inactive ? extend_pick<true, 1, EXACT>(lds, deep) : extend_pick<false, 1, EXACT>(lds, deep);
 }
 ExtendFn extend_variant(const SceneDev &sc, bool has_inactive) {
-    const bool lds = sc.lds_scene != 0, deep = sc.depth > 31u; // a 32-bit trail covers trees up to 31 levels deep
-    if (sc.prim_kind == 0) return has_inactive ? extend_pick<true, 0>(lds, deep) : extend_pick<false, 0>(lds, deep);
-    return has_inactive ? extend_pick<true, 1>(lds, deep) : extend_pick<false, 1>(lds, deep);
+    return sc.exact ? extend_variant_of<true>(sc, has_inactive) : extend_variant_of<false>(sc, has_inactive);
 }
 } // namespace
 
 hipError_t extend_blocks_per_cu(const SceneDev &scene, int *blocks) {
     hipError_t e = hipSuccess;
     if (scene.lds_bytes > 64u * 1024u) {
-        for (int v = 0; v < 2; ++v) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_variant(scene, v != 0)),
+        for (int v = 0; v < 4; ++v) { // both box tests: the context may switch between them later (decide_exact)
+            SceneDev sc = scene;
+            sc.exact = (v >> 1) & 1;
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(extend_variant(sc, (v & 1) != 0)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scene.lds_bytes));
             if (e != hipSuccess) return e;
         }
@@ -1588,15 +1639,18 @@ uint32_t bounce_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind
 
 namespace {
 using BounceFn = void (*)(BounceArgs);
-template <int MODE, int PRIM> BounceFn bounce_pick(bool lds_scene, bool deep) {
-    if (!lds_scene) return bounce_kernel<MODE, unsigned long long, PRIM, false>;
-    return deep ? bounce_kernel<MODE, unsigned long long, PRIM, true> : bounce_kernel<MODE, uint32_t, PRIM, true>;
+template <int MODE, int PRIM, bool EXACT> BounceFn bounce_pick(bool lds_scene, bool deep) {
+    if (!lds_scene) return bounce_kernel<MODE, unsigned long long, PRIM, false, EXACT>;
+    return deep ? bounce_kernel<MODE, unsigned long long, PRIM, true, EXACT> : bounce_kernel<MODE, uint32_t, PRIM, true, EXACT>;
+}
+template <bool EXACT> BounceFn bounce_variant_of(const SceneDev &sc, int mode) {
+    const bool lds = sc.lds_scene != 0, deep = sc.depth > 31u;
+    if (sc.prim_kind == 0) return mode == kBounceFirst ? bounce_pick<kBounceFirst, 0, EXACT>(lds, deep) : bounce_pick<kBounceMiddle, 0, EXACT>(lds, deep);
+    return mode == kBounceFirst ? bounce_pick<kBounceFirst, 1, EXACT>(lds, deep) : bounce_pick<kBounceMiddle, 1, EXACT>(lds, deep);
 }
 BounceFn bounce_variant(const SceneDev &sc, int mode) {
-    const bool lds = sc.lds_scene != 0, deep = sc.depth > 31u;
-    if (mode == kBounceLast) return bounce_kernel<kBounceLast, uint32_t, 0, false>; // no traversal: one variant
-    if (sc.prim_kind == 0) return mode == kBounceFirst ? bounce_pick<kBounceFirst, 0>(lds, deep) : bounce_pick<kBounceMiddle, 0>(lds, deep);
-    return mode == kBounceFirst ? bounce_pick<kBounceFirst, 1>(lds, deep) : bounce_pick<kBounceMiddle, 1>(lds, deep);
+    if (mode == kBounceLast) return bounce_kernel<kBounceLast, uint32_t, 0, false, false>; // no traversal: one variant
+    return sc.exact ? bounce_variant_of<true>(sc, mode) : bounce_variant_of<false>(sc, mode);
 }
 uint32_t bounce_dynamic_lds(const SceneDev &sc, int mode) {
     return mode == kBounceLast ? 4u * kBounceMiscWords : bounce_lds_bytes(sc.n_nodes, sc.n_spheres, sc.prim_kind, sc.lds_scene != 0);
@@ -1607,11 +1661,14 @@ hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks) {
     hipError_t e = hipSuccess;
     const uint32_t bytes = bounce_dynamic_lds(scene, kBounceMiddle);
     if (bytes > 64u * 1024u) {
-        for (int mode : {kBounceFirst, kBounceMiddle}) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(bounce_variant(scene, mode)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-            if (e != hipSuccess) return e;
-        }
+        for (int exact = 0; exact < 2; ++exact)
+            for (int mode : {kBounceFirst, kBounceMiddle}) {
+                SceneDev sc = scene;
+                sc.exact = static_cast<uint32_t>(exact);
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(bounce_variant(sc, mode)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+                if (e != hipSuccess) return e;
+            }
     }
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, bounce_variant(scene, kBounceMiddle), kExtendThreads, bytes);
 }
@@ -1674,6 +1731,11 @@ hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s) {
 
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s) {
     hipLaunchKernelGGL(accumulate_kernel, dim3(grid ? grid : 1u), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_frame(Control *ctl, const wfpt_frame_buffer &f, hipStream_t s) {
+    hipLaunchKernelGGL(set_frame_kernel, dim3(1), dim3(1), 0, s, ctl, f);
     return hipGetLastError();
 }
 
