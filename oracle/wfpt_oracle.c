@@ -1070,6 +1070,118 @@ void orc_sim_postpone(orc_ctx *c, uint32_t n, uint32_t Q, uint64_t out[8]) {
 
 /* Diagnostics for kernel design (not part of the chain): per-ray traversal step counts of the current ray
  * queue, so lane-utilisation models of the GPU schedule can be evaluated offline. */
+/* ---- MODEL of the device's default traversal (wfpt_kernels.hip: trace_ray_conservative; wfpt_api.hip: build_nodes_ch), kept here
+ * so that the hunt for rays on which a conservative box test could change the reported hit runs on the CPU, over millions of
+ * rays, without a GPU. Not part of the oracle proper: the reference's traversal is trace_ray_bvh above. Same arithmetic as the
+ * device (fmaf = one fused multiply-add, -ffp-contract=off elsewhere): node boxes as centre / half-extent, the half-extent grown
+ * by 2^-19 * extent per axis; per axis tc = fma(c, b, -(o b)), entry = fma(h, -|b|, tc), exit = fma(h, |b|, tc);
+ * entered <=> max(entry, 0) <= min(exit, nearest). */
+#include <math.h>
+static float model_up(double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, INFINITY); return f; }
+static void model_box(const orc_bvh_node *nd, const float extent[3], float c3[3], float h3[3]) {
+    for (int ax = 0; ax < 3; ax++) {
+        double lo = nd->aabb_min[ax], hi = nd->aabb_max[ax];
+        float c = (float)(0.5 * (lo + hi));
+        double h = fmax((double)c - lo, hi - (double)c);
+        c3[ax] = c;
+        h3[ax] = model_up((double)model_up(h) + ldexp((double)extent[ax], -19));
+    }
+}
+static int orc_leaf_rejected(const orc_bvh_node *node, const orc_ray *ray, float nearest_hit) { /* ex:165-179 as a boolean */
+    float tmin = -INFINITY, tmax = INFINITY;
+    for (int ax = 0; ax < 3; ax++) {
+        float t1 = (node->aabb_min[ax] - ray->origin[ax]) * ray->inv_direction[ax];
+        float t2 = (node->aabb_max[ax] - ray->origin[ax]) * ray->inv_direction[ax];
+        if (ax == 0) { tmin = orc_min(t1, t2); tmax = orc_max(t1, t2); }
+        else { tmin = orc_max(orc_min(t1, t2), tmin); tmax = orc_min(orc_max(t1, t2), tmax); }
+    }
+    return tmin > tmax || tmax <= 0.0f || tmin > nearest_hit;
+}
+typedef struct { float b[3], no[3], ab[3]; } model_ray;
+static int model_enter(const float c3[3], const float h3[3], const model_ray *r, float nearest, float *t_in) {
+    float in = -INFINITY, out = INFINITY;
+    for (int ax = 0; ax < 3; ax++) {
+        float tc = fmaf(c3[ax], r->b[ax], r->no[ax]);
+        in = orc_max(in, fmaf(h3[ax], -r->ab[ax], tc));
+        out = orc_min(out, fmaf(h3[ax], r->ab[ax], tc));
+    }
+    *t_in = in;
+    return orc_max(in, 0.0f) <= orc_min(out, nearest);
+}
+static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float extent[3], int leaf_exact, orc_hit_payload *hit) {
+    model_ray r;
+    for (int ax = 0; ax < 3; ax++) {
+        float inv = 1.0f / ray->direction[ax];
+        r.b[ax] = orc_min(orc_max(inv, -1e30f), 1e30f);
+        r.no[ax] = -(ray->origin[ax] * r.b[ax]);
+        r.ab[ax] = fabsf(r.b[ax]);
+    }
+    float nearest = 1e30f;
+    orc_hit_payload temp;
+    memset(&temp, 0, sizeof temp);
+    uint32_t stack[ORC_MAX_STACK], sp = 0, node = 0;
+    for (;;) {
+        const orc_bvh_node *nd = &c->nodes[node];
+        if (nd->prim_count > 0) {
+            /* the leaf's own box with the reference's arithmetic (the device recomputes it from the primitives; wfpt_create
+             * checks that this equals the node's box); the root's box is never tested (ex:84) */
+            if (node == 0 || !leaf_exact || !orc_leaf_rejected(nd, ray, nearest)) {
+                for (uint32_t i = 0; i < nd->prim_count; i++) {
+                    orc_hit_payload nh;
+                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) { nearest = nh.t; temp = nh; }
+                }
+            }
+            if (sp == 0) break;
+            node = stack[--sp];
+            continue;
+        }
+        float cl[3], hl[3], cr[3], hr[3], l_in, r_in;
+        model_box(&c->nodes[nd->left_first], extent, cl, hl);
+        model_box(&c->nodes[nd->left_first + 1], extent, cr, hr);
+        int hit_l = model_enter(cl, hl, &r, nearest, &l_in), hit_r = model_enter(cr, hr, &r, nearest, &r_in);
+        if (!(hit_l || hit_r)) {
+            if (sp == 0) break;
+            node = stack[--sp];
+        } else {
+            int go_right = hit_r && (!hit_l || l_in > r_in);
+            if (hit_l && hit_r) {
+                if (sp >= ORC_MAX_STACK) { fprintf(stderr, "oracle: model stack overflow\n"); abort(); }
+                stack[sp++] = nd->left_first + (go_right ? 0u : 1u);
+            }
+            node = nd->left_first + (go_right ? 1u : 0u);
+        }
+    }
+    if (nearest < 1e30f) { *hit = temp; return 1; }
+    return 0;
+}
+/* Traces rays 0..n-1 of the ray queue with the reference's traversal and with the model; writes up to max_out records
+ * (ray index, kind) of rays whose result differs (leaf_exact = 0: the model WITHOUT the exact test of leaf boxes, i.e. every
+ * box merely conservative -- the variant that is NOT equivalent to the reference, kept to show the counter-example): kind 1 = the model reports a hit the reference does not, 2 = the reference
+ * reports a hit the model does not, 3 = both hit, different t or primitive. Returns the number of differing rays. */
+uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[3], int leaf_exact, uint32_t *out, uint32_t max_out) {
+    uint32_t count = 0;
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t idx = 0; idx < (int64_t)n; idx++) {
+        const orc_ray *ray = &c->rays[idx];
+        if (ray->pixel_idx == ORC_INACTIVE_PIXEL) continue;
+        trace_stat st = {0, 0, 0};
+        orc_hit_payload a, b;
+        memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+        int ha = trace_ray_bvh(c, ray, &a, &st), hb = trace_ray_model(c, ray, extent, leaf_exact, &b);
+        int kind = 0;
+        if (hb && !ha) kind = 1;
+        else if (ha && !hb) kind = 2;
+        else if (ha && hb && (memcmp(&a.t, &b.t, 4) != 0 || a.sphere_idx != b.sphere_idx)) kind = 3;
+        if (kind) {
+            uint32_t k;
+#pragma omp atomic capture
+            k = count++;
+            if (k < max_out) { out[2 * k] = (uint32_t)idx; out[2 * k + 1] = (uint32_t)kind; }
+        }
+    }
+    return count;
+}
+
 void orc_ray_steps(orc_ctx *c, uint32_t n, uint16_t *inner_steps, uint16_t *leaf_steps) {
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int64_t idx = 0; idx < (int64_t)n; idx++) {

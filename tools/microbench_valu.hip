@@ -19,7 +19,7 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-struct Stamp { unsigned long long cycles, real; };
+struct Stamp { unsigned long long cycles, real, r0, r1; };
 typedef float v4f __attribute__((ext_vector_type(4))); // a 128-bit VGPR tuple inline asm can name
 
 enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW, N_KINDS };
@@ -36,7 +36,7 @@ enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, 
 #define I_SQRT(x) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x))
 #define I_ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(a))
 #define I_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(a))
-#define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc))
+#define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc")
 
 #define REP16(OP) OP(x[0]); OP(x[1]); OP(x[2]); OP(x[3]); OP(x[4]); OP(x[5]); OP(x[6]); OP(x[7]); OP(x[8]); OP(x[9]); OP(x[10]); OP(x[11]); OP(x[12]); OP(x[13]); OP(x[14]); OP(x[15])
 
@@ -131,7 +131,7 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += x[k];
     if (s == 123.456f) sink[0] = s; // keeps everything live, never true
-    if ((threadIdx.x & 63u) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = {t1 - t0, r1 - r0};
+    if ((threadIdx.x & 63u) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = {t1 - t0, r1 - r0, r0, r1};
 }
 
 struct Row { std::string name; int insts_per_trip; };
@@ -152,8 +152,9 @@ template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_o
             CK(hipEventRecord(e0)); for (int k = 0; k < 8; ++k) launch(trips); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1)); held += ms;
         }
-        launch(trips);
+        CK(hipEventRecord(e0)); launch(trips); CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
+        float launch_ms = 0; CK(hipEventElapsedTime(&launch_ms, e0, e1));
         std::vector<Stamp> h(static_cast<size_t>(blocks) * 4);
         CK(hipMemcpy(h.data(), d_out, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
         std::vector<double> cyc, clk;
@@ -162,8 +163,19 @@ template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_o
         std::nth_element(clk.begin(), clk.begin() + clk.size() / 2, clk.end());
         const double c = cyc[cyc.size() / 2], f = clk[clk.size() / 2];
         const double per_simd = c / (static_cast<double>(trips) * insts_per_trip * waves_per_simd);
-        printf("%-34s waves/SIMD %d: %7.3f cycles/instr/SIMD  (one wave: %6.2f cycles/instr)  clock %.3f GHz  %6.3f ns/instr/SIMD\n", name,
-               waves_per_simd, per_simd, c / (trips * insts_per_trip), f * 1e-9, per_simd / (f * 1e-9));
+        // were all waves really resident together? fraction of the waves whose [start, end] holds the median mid-point
+        std::vector<double> mid;
+        for (const Stamp &s : h) mid.push_back(0.5 * (static_cast<double>(s.r0) + static_cast<double>(s.r1)));
+        std::nth_element(mid.begin(), mid.begin() + mid.size() / 2, mid.end());
+        const double m = mid[mid.size() / 2];
+        size_t together = 0;
+        for (const Stamp &s : h) together += (static_cast<double>(s.r0) <= m && m <= static_cast<double>(s.r1)) ? 1 : 0;
+        // chip-wide rate from the launch's wall time (hipEvents), no assumption about placement at all
+        const double chip = static_cast<double>(h.size()) * trips * insts_per_trip / (launch_ms * 1e-3);
+        printf("%-34s waves/SIMD %d: %7.3f cycles/instr/SIMD  (one wave: %6.2f cycles/instr)  clock %.3f GHz  %6.3f ns/instr/SIMD | %3.0f%% of the waves "
+               "resident together, launch %.2f ms = %.3f T wave-instr/s chip-wide = %.3f per ns per SIMD\n", name,
+               waves_per_simd, per_simd, c / (trips * insts_per_trip), f * 1e-9, per_simd / (f * 1e-9), 100.0 * together / h.size(), launch_ms,
+               chip * 1e-12, chip * 1e-9 / (4.0 * cus));
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
 }

@@ -593,6 +593,45 @@ bool build_nodes_ch(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float ca
     return true;
 }
 
+// The traversals that prune inner boxes freely (trace_ray_conservative, trace_ray4) test a LEAF's box with the reference's
+// arithmetic on a box they recompute from the leaf's primitives, and rely on the boxes of a BVH nesting. Both are facts about
+// the caller's tree, checked here: every leaf box equals the union of its primitives' boxes as the builder computes them
+// (sphere.rs:22-26 / the triangle policy of wfpt_host.cpp; update_node_bounds, bvh.rs:58-70 -- values compared with ==, so
+// the sign of a zero bound is free), and every inner box contains its children's. A tree that fails is walked with the
+// reference's own test everywhere (decide_exact).
+bool tree_is_recomputable(const wfpt_bvh_node *nodes, uint32_t n_nodes, const wfpt_sphere *spheres, const wfpt_triangle *triangles) {
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        if (i == 1) continue;
+        const wfpt_bvh_node &nd = nodes[i];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (nd.prim_count > 0) {
+            for (uint32_t k = 0; k < nd.prim_count; ++k) {
+                const uint32_t p = nd.left_first + k;
+                for (int ax = 0; ax < 3; ++ax) {
+                    float a, b;
+                    if (spheres) {
+                        a = spheres[p].center[ax] - spheres[p].radius;
+                        b = spheres[p].center[ax] + spheres[p].radius;
+                    } else {
+                        const float v0 = triangles[p].v0[ax], v1 = triangles[p].v0[ax] + triangles[p].e1[ax], v2 = triangles[p].v0[ax] + triangles[p].e2[ax];
+                        a = std::fmin(std::fmin(v0, v1), v2);
+                        b = std::fmax(std::fmax(v0, v1), v2);
+                    }
+                    lo[ax] = std::fmin(lo[ax], a);
+                    hi[ax] = std::fmax(hi[ax], b);
+                }
+            }
+            for (int ax = 0; ax < 3; ++ax)
+                if (!(lo[ax] == nd.aabb_min[ax]) || !(hi[ax] == nd.aabb_max[ax])) return false;
+        } else {
+            for (uint32_t c = nd.left_first; c <= nd.left_first + 1u; ++c)
+                for (int ax = 0; ax < 3; ++ax)
+                    if (!(nodes[c].aabb_min[ax] >= nd.aabb_min[ax]) || !(nodes[c].aabb_max[ax] <= nd.aabb_max[ax])) return false;
+        }
+    }
+    return true;
+}
+
 // ray origins the camera can produce: |position| + the lens radius (gr:73-79), per axis
 void camera_reach(const wfpt_gpu_camera &cam, float reach[3]) {
     const float r = cam.defocus_radius > 0.0f ? cam.defocus_radius : 0.0f;
@@ -605,7 +644,7 @@ void decide_exact(wfpt_ctx *c, const float cam_reach[3]) {
     bool exact = (c->p.flags & WFPT_FLAG_EXACT_TRAVERSAL) != 0 || (c->scene.lds_scene && !c->ch_ok) || c->far_rays;
     for (int ax = 0; ax < 3 && !exact && c->ch_ok; ++ax)
         if (!(cam_reach[ax] <= 4.0f * c->extent[ax])) exact = true;
-    c->scene.exact = exact ? 1u : 0u;
+    c->scene.exact = exact ? 1u : 0u; // (scenes beyond LDS: the four-wide nodes exist only when the tree passed tree_is_recomputable)
 }
 
 void free_scene(wfpt_ctx *c) {
@@ -681,12 +720,13 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
     const bool flag_exact = (c->p.flags & WFPT_FLAG_EXACT_TRAVERSAL) != 0;
     float reach[3];
     camera_reach(*camera, reach);
+    const bool recomputable = !flag_exact && tree_is_recomputable(nodes, n_nodes, spheres, triangles);
     if (lds_scene) {
         std::vector<uint16_t> p16(pair_parent.begin(), pair_parent.end());
         WFPT_HIP(c, dmalloc(&c->d_pair_parent, p16.size()));
         WFPT_HIP(c, hipMemcpy(c->d_pair_parent, p16.data(), sizeof(uint16_t) * p16.size(), hipMemcpyHostToDevice));
         std::vector<float4> ch;
-        if (build_nodes_ch(nodes, n_nodes, reach, ch, c->extent)) {
+        if (recomputable && build_nodes_ch(nodes, n_nodes, reach, ch, c->extent)) {
             WFPT_HIP(c, dmalloc(&c->d_nodes_ch, ch.size()));
             WFPT_HIP(c, hipMemcpy(c->d_nodes_ch, ch.data(), sizeof(float4) * ch.size(), hipMemcpyHostToDevice));
             c->scene.nodes_ch = c->d_nodes_ch;
@@ -697,7 +737,7 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
         WFPT_HIP(c, hipMemcpy(c->d_pair_parent32, pair_parent.data(), sizeof(uint32_t) * pair_parent.size(), hipMemcpyHostToDevice));
     }
     // four-wide nodes for the HBM-resident traversal (not the reference's walk: WFPT_FLAG_EXACT_TRAVERSAL keeps the binary tree)
-    if (!lds_scene && !(c->p.flags & WFPT_FLAG_BINARY_BVH) && !flag_exact) {
+    if (!lds_scene && !(c->p.flags & WFPT_FLAG_BINARY_BVH) && recomputable) {
         std::vector<Node4> n4;
         if (collapse_bvh4(nodes, n_nodes, n4, c->depth4)) {
             WFPT_HIP(c, dmalloc(&c->d_nodes4, 4 * n4.size()));
@@ -724,6 +764,7 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
     c->scene.lds_scene = lds_scene ? 1u : 0u;
     c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres, prim_kind, lds_scene);
     c->scene.depth = bvh_depth;
+    c->scene.root_leaf = nodes[0].prim_count > 0 ? 1u : 0u;
     c->far_rays = false;
     decide_exact(c, reach);
 

@@ -119,6 +119,7 @@ struct SceneDev {
     // half-extent grown by more than the box test's rounding error (trace_ray_conservative); staged instead of `nodes`
     const float4 *nodes_ch;
     uint32_t exact; // 1: WFPT_FLAG_EXACT_TRAVERSAL (or a fallback to it): the reference's box test and 1e30 miss value
+    uint32_t root_leaf; // the root is a leaf: its box is never tested (ex:84), so neither is it by the leaf-box test of the free walks
 };
 
 constexpr uint32_t kStack4Lds = 16; // stack entries of the four-wide traversal kept in LDS (per lane)

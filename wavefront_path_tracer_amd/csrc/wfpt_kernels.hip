@@ -158,6 +158,22 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(GenerateArgs a) {
 // comparison leaves such a pair alone: 11 % fewer visits for primary rays, 7 % for the others (oracle model,
 // tools/model_schedule.py), the hits unchanged.
 constexpr float kBoxMiss = 3.0e38f;
+// the slab distances of ex:165-178, in the reference's operation order
+__device__ __forceinline__ void slab_range(float4 bmin, float4 bmax, float ox, float oy, float oz, float ix, float iy, float iz,
+                                           float &tmin_out, float &tmax_out) {
+    const float t_x_min = (bmin.x - ox) * ix;
+    const float t_x_max = (bmax.x - ox) * ix;
+    float tmin = min_(t_x_min, t_x_max);
+    float tmax = max_(t_x_min, t_x_max);
+    const float t_y_min = (bmin.y - oy) * iy;
+    const float t_y_max = (bmax.y - oy) * iy;
+    tmin = max_(min_(t_y_min, t_y_max), tmin);
+    tmax = min_(max_(t_y_min, t_y_max), tmax);
+    const float t_z_min = (bmin.z - oz) * iz;
+    const float t_z_max = (bmax.z - oz) * iz;
+    tmin_out = max_(min_(t_z_min, t_z_max), tmin);
+    tmax_out = min_(max_(t_z_min, t_z_max), tmax);
+}
 template <bool EXACT>
 __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox, float oy, float oz, float ix,
                                               float iy, float iz, float nearest) {
@@ -305,6 +321,35 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
     }
 }
 
+// The box of primitive `idx` exactly as the builder computes it (sphere.rs:22-26: centre -+ radius; triangles, build extension:
+// min / max over v0, v0 + e1, v0 + e2), grown into [lo, hi] like update_node_bounds does (bvh.rs:58-70). wfpt_create checks that
+// the caller's leaf boxes are bit for bit what this gives (leaf_boxes_recomputable, wfpt_api.hip).
+template <int PRIM>
+__device__ __forceinline__ void grow_prim_box(const float4 *geom, uint32_t idx, float3_ &lo, float3_ &hi) {
+    if (PRIM == 0) {
+        const float4 s = geom[idx];
+        lo = {min_(lo.x, s.x - s.w), min_(lo.y, s.y - s.w), min_(lo.z, s.z - s.w)};
+        hi = {max_(hi.x, s.x + s.w), max_(hi.y, s.y + s.w), max_(hi.z, s.z + s.w)};
+    } else {
+        const float4 v0 = geom[3u * idx], e1 = geom[3u * idx + 1u], e2 = geom[3u * idx + 2u];
+        const float bx = v0.x + e1.x, by = v0.y + e1.y, bz = v0.z + e1.z, cx = v0.x + e2.x, cy = v0.y + e2.y, cz = v0.z + e2.z;
+        lo = {min_(lo.x, min_(min_(v0.x, bx), cx)), min_(lo.y, min_(min_(v0.y, by), cy)), min_(lo.z, min_(min_(v0.z, bz), cz))};
+        hi = {max_(hi.x, max_(max_(v0.x, bx), cx)), max_(hi.y, max_(max_(v0.y, by), cy)), max_(hi.z, max_(max_(v0.z, bz), cz))};
+    }
+}
+// The reference's own test (ex:164-183) of the box of a LEAF holding primitives [first, first + count).
+// Every traversal below that is free in how it prunes INNER boxes applies this before it tests a leaf's primitives: see
+// trace_ray_conservative for why that makes the set of tested primitives exactly the reference's.
+template <int PRIM>
+__device__ __forceinline__ bool leaf_box_passes(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float ix,
+                                                float iy, float iz, float nearest) {
+    float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
+    float tmin, tmax;
+    slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
+    return !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
+}
+
 template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH, bool EXACT>
 __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *prim_geom, const ParentT *pair_parent,
                                           uint32_t *stack_column, float ox, float oy, float oz, float dx, float dy,
@@ -361,25 +406,35 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     return nearest < 1e30f; // ex:157
 }
 
-// ---- the LDS-resident traversal as it runs by default: same walk, CONSERVATIVE box test ---------------------------
-// What `extend` reports is the minimum, over the primitives whose EXACT test (hit_prim, ex:185-210) accepts, of their t:
-// a box test only has to say "maybe" for every box the reference's test (ex:164-183) would enter. Here a box is kept as
-// centre c and half-extent h (SceneDev::nodes_ch, built at wfpt_create), h grown on the host by MORE than this test's
-// own rounding error can reach (conservative_margin(), wfpt_api.hip): for every ray whose origin lies within four scene
-// extents of the origin, computed entry distance <= the exact box's entry distance and computed exit distance >= its
-// exit distance. So every primitive the reference tests is tested here too, and the hits are the reference's by
-// construction, not by luck -- for spheres AND triangles (wfpt_create falls back to the exact test when a camera or an
-// injected ray lies outside that range, or when a box is not finite).
+// ---- the LDS-resident traversal as it runs by default: same walk, CONSERVATIVE test of inner boxes, EXACT test of leaf boxes
+// What must not change is the set of primitives whose exact test (hit_prim, ex:185-210) runs: that test rounds too (its
+// discriminant cancels ~1e-7 of b^2), so a sphere "hit" can be reported for a ray that passes ~1e-4 outside the sphere -- and
+// the reference never sees it, because the ray misses the sphere's BOX and the leaf is never entered. (Found by
+// tools/hunt_conservative.py: with every box grown, 2 rays in 1.6e8 reported such a hit; in the dispatch-keyed RNG mode one
+// changed hit re-keys the rest of the sample.) So boxes are filters the result depends on, and they are treated in two classes:
+//   * LEAF boxes are tested with the reference's own arithmetic (leaf_box_passes) when the walk arrives at the leaf;
+//   * INNER boxes only have to say "maybe" whenever the reference's test would enter them.
+// That is enough, because the reference's test is MONOTONE in the box: IEEE subtraction and multiplication by a fixed inverse
+// are monotone, so for nested boxes L inside A (a BVH's boxes nest in float coordinates; checked at wfpt_create) every plane
+// distance of A lies outside the corresponding one of L and "the reference enters L" implies "the reference enters A" (its
+// geometric part: tmin <= tmax, tmax > 0). Hence the reference tests exactly the primitives of the leaves whose own box passes
+// its test -- and so does any walk that reaches every such leaf and applies that test there. (The reference's third condition,
+// tmin > nearest, only skips boxes that cannot hold a nearer hit; which of two primitives with bit-equal t is reported, and a
+// hit that is nearer than its own box's entry distance by rounding while another hit lies in between, are the two corners in
+// which the ORDER of visits can show; the order below follows the reference's rule on conservative distances.)
+// Inner boxes: a box is kept as centre c and half-extent h (SceneDev::nodes_ch, built at wfpt_create), h grown on the host by
+// MORE than this test's own rounding error can reach (build_nodes_ch, wfpt_api.hip): for every ray whose origin lies within
+// four scene extents of the origin, computed entry distance <= the exact box's and computed exit distance >= its exit
+// distance. (wfpt_create falls back to the exact test when a camera or an injected ray lies outside that range, when a box
+// is not finite, or when the caller's leaf boxes are not what leaf_box_passes recomputes.)
 //   per axis: tc = c * inv - o * inv (one fma against the per-ray constant -(o * inv)),
 //             t_entry = tc - h * |inv|, t_exit = tc + h * |inv| (one fma each; the sign of inv needs no min / max),
 //   entered  <=> max(t_entry over axes, 0) <= min(t_exit over axes, nearest)
 // 9 fma + max3 + min3 + max + min + compare per box where the reference form costs 6 sub/mul pairs + 12 min / max + 3
 // compares. The walk is the reference's (root box never tested; both children entered: nearer entry first, ties keep
-// the left child; the far one pending), with the two places where a conservative test is free to differ: a pair of
-// boxes the ray misses both of is left alone while nothing is hit yet (the reference's `1e30 > 1e30`, see kBoxMiss),
-// and a far child whose entry distance equals `nearest` exactly stays pending (the reference drops it at `<`; it cannot
-// hold a nearer hit). Infinite inverses (a direction component that is exactly zero) are clamped to +-1e30: the
-// two planes of such an axis then read "always" or "never" like the reference's +-inf, without inf - inf.
+// the left child; the far one pending). Infinite inverses (a direction component that is exactly zero) are clamped to
+// +-1e30 for the inner boxes: the two planes of such an axis then read "always" or "never" like the reference's +-inf,
+// without inf - inf; the leaf test uses the unclamped inverse, as the reference does.
 template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
                                                        float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
@@ -425,9 +480,10 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
             }
         }
         if (alive && budget-- == 0) alive = false;
-        if (alive) { // leaf (ex:86-103)
-            for (uint32_t i = 0; i < tr.prim_count; ++i)
-                hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+        if (alive) { // leaf (ex:86-103); the root's own box is never tested (ex:84)
+            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest))
+                for (uint32_t i = 0; i < tr.prim_count; ++i)
+                    hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
@@ -504,7 +560,7 @@ __device__ __forceinline__ Visit4 visit4(const float4 *nodes4, uint32_t cur, flo
 
 template <int PRIM>
 __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *prim_geom, Stack4 st, float ox, float oy, float oz, float dx,
-                                           float dy, float dz, uint32_t max_steps, float &t_out, uint32_t &prim_out) {
+                                           float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz;
     float nearest = 1e30f;
@@ -530,9 +586,12 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf child: kLeafFlag | count << 28 | first
+            // the quantised boxes above are LARGER than the caller's: the leaf's own box decides, with the reference's arithmetic
+            // (see trace_ray_conservative), whether its primitives are tested
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            for (uint32_t i = 0; i < count; ++i)
-                hit_prim<PRIM>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest))
+                for (uint32_t i = 0; i < count; ++i)
+                    hit_prim<PRIM>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
     }
@@ -630,7 +689,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
                 st.lds = s_stack + threadIdx.x;
                 st.stride = a.scene.spill_stride;
                 st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
-                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
             } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
                                                                             s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
@@ -1241,7 +1300,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 st.lds = L.stack + threadIdx.x;
                 st.stride = a.scene.spill_stride;
                 st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
-                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
             } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
                                                                             ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
@@ -1404,8 +1463,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 fin = true;
             } else {
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-                for (uint32_t i = 0; i < count; ++i)
-                    hit_prim<PRIM>(a.scene.prim_geom, first + i, ox, oy, oz, dx, dy, dz, aa, nearest, best);
+                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest)) // see trace_ray4
+                    for (uint32_t i = 0; i < count; ++i)
+                        hit_prim<PRIM>(a.scene.prim_geom, first + i, ox, oy, oz, dx, dy, dz, aa, nearest, best);
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
