@@ -22,7 +22,8 @@
 struct Stamp { unsigned long long cycles, real, r0, r1; };
 typedef float v4f __attribute__((ext_vector_type(4))); // a 128-bit VGPR tuple inline asm can name
 
-enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW, N_KINDS };
+enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW,
+            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, N_KINDS };
 
 // one instruction of the class on register x (a, b: loop-invariant VGPRs; m: an SGPR pair holding a lane mask)
 #define I_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
@@ -36,6 +37,18 @@ enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, 
 #define I_SQRT(x) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x))
 #define I_ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(a))
 #define I_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(a))
+#define I_MULF(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_ADDF(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_ANDB(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_LSHL(x) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x))
+#define I_BFE(x) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(x))
+#define I_CVTUB(x) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(x))
+#define I_ADDC(x) asm volatile("v_addc_co_u32 %0, %2, %0, %1, %2" : "+v"(x) : "v"(a), "s"(m))
+#define I_MOV(x) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(a))
+#define I_MED3(x) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_CNDVCC(x) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : )
+#define I_MINE64(x) asm volatile("v_min_f32_e64 %0, %0, |%1|" : "+v"(x) : "v"(a))
 #define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc")
 
 #define REP16(OP) OP(x[0]); OP(x[1]); OP(x[2]); OP(x[3]); OP(x[4]); OP(x[5]); OP(x[6]); OP(x[7]); OP(x[8]); OP(x[9]); OP(x[10]); OP(x[11]); OP(x[12]); OP(x[13]); OP(x[14]); OP(x[15])
@@ -69,6 +82,18 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
         if (KIND == SQRT) { REP16(I_SQRT); REP16(I_SQRT); REP16(I_SQRT); REP16(I_SQRT); }
         if (KIND == ADDU) { REP16(I_ADDU); REP16(I_ADDU); REP16(I_ADDU); REP16(I_ADDU); }
         if (KIND == LSHLADD) { REP16(I_LSHLADD); REP16(I_LSHLADD); REP16(I_LSHLADD); REP16(I_LSHLADD); }
+        if (KIND == MULF) { REP16(I_MULF); REP16(I_MULF); REP16(I_MULF); REP16(I_MULF); }
+        if (KIND == ADDF) { REP16(I_ADDF); REP16(I_ADDF); REP16(I_ADDF); REP16(I_ADDF); }
+        if (KIND == ANDB) { REP16(I_ANDB); REP16(I_ANDB); REP16(I_ANDB); REP16(I_ANDB); }
+        if (KIND == LSHL) { REP16(I_LSHL); REP16(I_LSHL); REP16(I_LSHL); REP16(I_LSHL); }
+        if (KIND == BFE) { REP16(I_BFE); REP16(I_BFE); REP16(I_BFE); REP16(I_BFE); }
+        if (KIND == CVTUB) { REP16(I_CVTUB); REP16(I_CVTUB); REP16(I_CVTUB); REP16(I_CVTUB); }
+        if (KIND == ADDC) { REP16(I_ADDC); REP16(I_ADDC); REP16(I_ADDC); REP16(I_ADDC); }
+        if (KIND == MOV) { REP16(I_MOV); REP16(I_MOV); REP16(I_MOV); REP16(I_MOV); }
+        if (KIND == MED3) { REP16(I_MED3); REP16(I_MED3); REP16(I_MED3); REP16(I_MED3); }
+        if (KIND == ANDOR) { REP16(I_ANDOR); REP16(I_ANDOR); REP16(I_ANDOR); REP16(I_ANDOR); }
+        if (KIND == CNDVCC) { REP16(I_CNDVCC); REP16(I_CNDVCC); REP16(I_CNDVCC); REP16(I_CNDVCC); }
+        if (KIND == MINE64) { REP16(I_MINE64); REP16(I_MINE64); REP16(I_MINE64); REP16(I_MINE64); }
         if (KIND == FMA_DEP) { // ONE dependent chain: latency, not throughput
 #pragma unroll
             for (int k = 0; k < 64; ++k) I_FMA(x[0]);
@@ -136,8 +161,9 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
 
 struct Row { std::string name; int insts_per_trip; };
 
+static bool quick = false;
 template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_out, float *d_sink, int cus) {
-    for (int waves_per_simd : {1, 2, 4, 8}) {
+    for (int waves_per_simd : (quick ? std::vector<int>{2, 8} : std::vector<int>{1, 2, 4, 8})) {
         const int blocks = cus * waves_per_simd; // 256-thread blocks = 4 waves = one per SIMD; waves_per_simd blocks per CU
         // pick the trip count for ~8 ms launches, then hold the load for >= 0.7 s before the measured launches
         uint32_t trips = 2000;
@@ -204,5 +230,18 @@ int main() {
     run<FMA_DSREAD>("64 v_fma + 4 ds_read_b128 (per VALU)", 64, d_out, d_sink, cus);
     run<VISIT_OLD>("visit, min/max planes (per VISIT)", 1, d_out, d_sink, cus);
     run<VISIT_NEW>("visit, centre/half planes (per VISIT)", 1, d_out, d_sink, cus);
+    quick = true; // more instruction classes, at 2 and 8 waves per SIMD
+    run<MULF>("v_mul_f32", 64, d_out, d_sink, cus);
+    run<ADDF>("v_add_f32", 64, d_out, d_sink, cus);
+    run<ANDB>("v_and_b32", 64, d_out, d_sink, cus);
+    run<LSHL>("v_lshlrev_b32", 64, d_out, d_sink, cus);
+    run<BFE>("v_bfe_u32", 64, d_out, d_sink, cus);
+    run<CVTUB>("v_cvt_f32_ubyte1", 64, d_out, d_sink, cus);
+    run<ADDC>("v_addc_co_u32 (sgpr carry)", 64, d_out, d_sink, cus);
+    run<MOV>("v_mov_b32", 64, d_out, d_sink, cus);
+    run<MED3>("v_med3_f32", 64, d_out, d_sink, cus);
+    run<ANDOR>("v_and_or_b32", 64, d_out, d_sink, cus);
+    run<CNDVCC>("v_cndmask_b32_e32 (vcc)", 64, d_out, d_sink, cus);
+    run<MINE64>("v_min_f32_e64 (abs modifier)", 64, d_out, d_sink, cus);
     return 0;
 }

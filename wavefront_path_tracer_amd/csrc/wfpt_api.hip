@@ -412,7 +412,7 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     };
     c->cur = 0;
     const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
-    if (c->fused && c->rec_dense) {
+    if (c->fused && c->rec_dense && !c->scene.exact) {
         // HBM-resident scene: traversal with dynamic lane refill. Per wavefront: (miss_kernel of the previous one) |
         // refill-trace into dense per-ray records | compact into the queues | scan; then shade+miss of the last one.
         const uint32_t grid = c->cus * c->bounce_blocks_per_cu;
@@ -557,12 +557,8 @@ int stage_end(wfpt_ctx *c, int stage) {
 // |o| <= 4 extent, |c|, h <= extent: less than half of margin * |b|. So the computed entry distance never exceeds the
 // exact box's and the computed exit distance never falls below it: the test can only say "enter" more often than the
 // reference's (ex:164-183), never less. Returns false (=> the exact test is used) when a box is not finite.
-bool build_nodes_ch(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float cam_reach[3], std::vector<float4> &out, float extent[3]) {
-    auto up = [](double v) { // smallest float >= v
-        float f = static_cast<float>(v);
-        if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
-        return f;
-    };
+// per axis: a bound on every |coordinate| of the scene and on a quarter of the camera's reach; false if a box is not finite
+bool scene_extent(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float cam_reach[3], float extent[3]) {
     for (int ax = 0; ax < 3; ++ax) {
         float e = 0.25f * cam_reach[ax];
         for (uint32_t i = 0; i < n_nodes; ++i) {
@@ -574,6 +570,15 @@ bool build_nodes_ch(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float ca
         if (!(e < 1e30f)) return false;
         extent[ax] = e;
     }
+    return true;
+}
+bool build_nodes_ch(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float cam_reach[3], std::vector<float4> &out, float extent[3]) {
+    auto up = [](double v) { // smallest float >= v
+        float f = static_cast<float>(v);
+        if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
+        return f;
+    };
+    if (!scene_extent(nodes, n_nodes, cam_reach, extent)) return false;
     out.resize(2 * static_cast<size_t>(n_nodes));
     for (uint32_t i = 0; i < n_nodes; ++i) {
         float c3[3], h3[3];
@@ -642,6 +647,7 @@ void camera_reach(const wfpt_gpu_camera &cam, float reach[3]) {
 // boxes' error bound does not cover the rays at hand) or the conservative one.
 void decide_exact(wfpt_ctx *c, const float cam_reach[3]) {
     bool exact = (c->p.flags & WFPT_FLAG_EXACT_TRAVERSAL) != 0 || (c->scene.lds_scene && !c->ch_ok) || c->far_rays;
+    // (scenes beyond LDS without four-wide nodes walk the binary tree with the reference's arithmetic anyway)
     for (int ax = 0; ax < 3 && !exact && c->ch_ok; ++ax)
         if (!(cam_reach[ax] <= 4.0f * c->extent[ax])) exact = true;
     c->scene.exact = exact ? 1u : 0u; // (scenes beyond LDS: the four-wide nodes exist only when the tree passed tree_is_recomputable)
@@ -739,10 +745,16 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
     // four-wide nodes for the HBM-resident traversal (not the reference's walk: WFPT_FLAG_EXACT_TRAVERSAL keeps the binary tree)
     if (!lds_scene && !(c->p.flags & WFPT_FLAG_BINARY_BVH) && recomputable) {
         std::vector<Node4> n4;
-        if (collapse_bvh4(nodes, n_nodes, n4, c->depth4)) {
-            WFPT_HIP(c, dmalloc(&c->d_nodes4, 4 * n4.size()));
-            WFPT_HIP(c, hipMemcpy(c->d_nodes4, n4.data(), sizeof(Node4) * n4.size(), hipMemcpyHostToDevice));
-            c->scene.nodes4 = c->d_nodes4;
+        float margin[3];
+        if (scene_extent(nodes, n_nodes, reach, c->extent)) {
+            for (int ax = 0; ax < 3; ++ax) margin[ax] = std::nextafterf(std::ldexp(c->extent[ax], -19), INFINITY);
+            if (collapse_bvh4(nodes, n_nodes, margin, n4, c->depth4)) {
+                WFPT_HIP(c, dmalloc(&c->d_nodes4, 4 * n4.size()));
+                WFPT_HIP(c, hipMemcpy(c->d_nodes4, n4.data(), sizeof(Node4) * n4.size(), hipMemcpyHostToDevice));
+                c->scene.nodes4 = c->d_nodes4;
+                c->scene.tile_n = static_cast<uint32_t>(std::min<size_t>(n4.size(), kTileNodesMax));
+                c->ch_ok = true; // the one-fma plane distances of visit4 carry the same rounding allowance as the LDS walk's
+            }
         }
     }
     const bool want_dense = c->fused && c->scene.nodes4 && !(c->p.flags & WFPT_FLAG_NO_REFILL);

@@ -24,15 +24,18 @@ struct Node4 {
     uint8_t qlo[3][4]; // [axis][child]: lower plane = origin + qlo * scale, rounded down
     uint8_t qhi[3][4]; // upper plane = origin + qhi * scale, rounded up
     uint32_t child[4];
-    uint32_t pad1[2];
+    uint16_t scale_hi[3]; // the same scales as the upper 16 bits of their float (a power of two has no more): one shift / mask to decode
+    uint16_t pad1;
 };
-static_assert(sizeof(Node4) == 64 && offsetof(Node4, qlo) == 16 && offsetof(Node4, child) == 40, "a four-wide node is one 64-byte line");
+static_assert(sizeof(Node4) == 64 && offsetof(Node4, qlo) == 16 && offsetof(Node4, child) == 40 && offsetof(Node4, scale_hi) == 56,
+              "a four-wide node is one 64-byte line");
 constexpr uint32_t kLeafFlag = 0x80000000u, kEmptyChild = 0xffffffffu;
 constexpr uint32_t kLeafCountShift = 28, kLeafMaxCount = 6, kLeafFirstMask = (1u << kLeafCountShift) - 1u; // count 7 would make an all-ones word possible
 
-// Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into quantised four-wide nodes. Returns false
-// when a leaf cannot be written as a child word or a box is not finite: the caller then keeps the binary traversal.
-// `depth4` = levels of four-wide nodes below the root node.
-bool collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vector<Node4> &out, uint32_t &depth4);
+// Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into quantised four-wide nodes, numbered breadth
+// first, every child box grown by `margin` per axis before it is quantised. Returns false when a leaf cannot be written as a
+// child word or a box is not finite: the caller then keeps the binary traversal. `depth4` = levels of four-wide nodes below
+// the root node.
+bool collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float margin[3], std::vector<Node4> &out, uint32_t &depth4);
 
 } // namespace wfpt

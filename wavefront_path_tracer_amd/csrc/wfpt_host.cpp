@@ -253,12 +253,14 @@ const char *const kStageNames[WFPT_STAGE_COUNT] = {"generate_rays",    "extend",
 } // namespace
 
 // Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into four-wide nodes: the children of node N are
-// its grandchildren where a child is an inner node, and the child itself where it is a leaf; the child boxes are
-// quantised to 8 bits per plane in the frame of their union, rounded OUTWARDS under the device's own dequantisation
-// arithmetic (plane = fmaf(q, 2^e, origin)), so a quantised box always encloses the caller's. Returns false when a leaf
-// cannot be written as a child word (more than wfpt::kLeafMaxCount primitives or an index beyond 28 bits) or a box is not
-// finite: the caller then keeps the binary traversal. `depth4` = levels of four-wide nodes below the root node.
-bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vector<wfpt::Node4> &out, uint32_t &depth4) {
+// its grandchildren where a child is an inner node, and the child itself where it is a leaf; the child boxes, each grown by
+// `margin` per axis (the rounding allowance of the device's one-fma plane distances, see visit4), are quantised to 8 bits per
+// plane in the frame of their union, rounded OUTWARDS under the dequantisation arithmetic (plane = fmaf(q, 2^e, origin)), so
+// a quantised box always encloses the caller's box plus the margin. Nodes are numbered BREADTH FIRST: any prefix of the array
+// is a top of the tree (the traversal stages such a prefix in LDS). Returns false when a leaf cannot be written as a child
+// word (more than wfpt::kLeafMaxCount primitives or an index beyond 28 bits) or a box is not finite: the caller then keeps
+// the binary traversal. `depth4` = levels of four-wide nodes below the root node.
+bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float margin[3], std::vector<wfpt::Node4> &out, uint32_t &depth4) {
     out.clear();
     depth4 = 0;
     auto leaf_word = [&](const wfpt_bvh_node &nd, uint32_t &w) {
@@ -272,8 +274,8 @@ bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vect
         for (int ax = 0; ax < 3; ++ax) {
             float lo = INFINITY, hi = -INFINITY;
             for (uint32_t k = 0; k < n_kids; ++k) {
-                lo = std::min(lo, nodes[kids[k]].aabb_min[ax]);
-                hi = std::max(hi, nodes[kids[k]].aabb_max[ax]);
+                lo = std::min(lo, nodes[kids[k]].aabb_min[ax] - margin[ax]);
+                hi = std::max(hi, nodes[kids[k]].aabb_max[ax] + margin[ax]);
             }
             if (!std::isfinite(lo) || !std::isfinite(hi) || hi < lo) return false;
             nd4.origin[ax] = lo;
@@ -287,7 +289,7 @@ bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vect
                 std::memcpy(&scale, &bits, 4);
                 bool fits = true;
                 for (uint32_t k = 0; k < n_kids && fits; ++k) {
-                    const float cmin = nodes[kids[k]].aabb_min[ax], cmax = nodes[kids[k]].aabb_max[ax];
+                    const float cmin = nodes[kids[k]].aabb_min[ax] - margin[ax], cmax = nodes[kids[k]].aabb_max[ax] + margin[ax];
                     int ql = static_cast<int>(std::floor((cmin - lo) / scale));
                     ql = std::min(std::max(ql, 0), 255);
                     while (ql > 0 && std::fmaf(static_cast<float>(ql), scale, lo) > cmin) --ql; // q = 0 gives lo <= cmin exactly
@@ -298,7 +300,7 @@ bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vect
                     nd4.qlo[ax][k] = static_cast<uint8_t>(ql);
                     nd4.qhi[ax][k] = static_cast<uint8_t>(qh);
                 }
-                if (fits) { nd4.exp[ax] = static_cast<uint8_t>(biased); break; }
+                if (fits) { nd4.exp[ax] = static_cast<uint8_t>(biased); nd4.scale_hi[ax] = static_cast<uint16_t>(biased << 7); break; }
             }
         }
         return true;
@@ -313,9 +315,8 @@ bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, std::vect
         return leaf_word(nodes[0], out[0].child[0]);
     }
     todo.push_back({0u, 0u, 0u});
-    while (!todo.empty()) {
-        const Item it = todo.back();
-        todo.pop_back();
+    for (size_t head = 0; head < todo.size(); ++head) { // first in, first out: slots are handed out level by level
+        const Item it = todo[head];
         depth4 = std::max(depth4, it.depth);
         uint32_t kids[4], n_kids = 0;
         const uint32_t l = nodes[it.bin].left_first;
@@ -353,7 +354,8 @@ extern "C" int wfpt_debug_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, uin
     if (!nodes || n_nodes == 0 || !counts) return WFPT_ERR_INVALID_ARGUMENT;
     std::vector<wfpt::Node4> n4;
     uint32_t depth4 = 0;
-    if (!wfpt::collapse_bvh4(nodes, n_nodes, n4, depth4)) return WFPT_ERR_UNSUPPORTED;
+    const float no_margin[3] = {0.0f, 0.0f, 0.0f};
+    if (!wfpt::collapse_bvh4(nodes, n_nodes, no_margin, n4, depth4)) return WFPT_ERR_UNSUPPORTED;
     // walk both trees together: four-wide node `slot` stands for binary inner node `bin`
     struct Item { uint32_t bin, slot; };
     std::vector<Item> todo;

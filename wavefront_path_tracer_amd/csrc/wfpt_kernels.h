@@ -113,6 +113,7 @@ struct SceneDev {
     // the binary tree. Stack entries beyond the LDS column spill to `stack_spill`, entry k of global thread g at
     // [k * spill_stride + g].
     const float4 *nodes4;
+    uint32_t tile_n;              // nodes4[0 .. tile_n) = the top of the tree (breadth-first numbering), staged in LDS by refill_kernel
     uint32_t *stack_spill;
     uint32_t spill_stride;
     // LDS-resident scenes, default traversal: every node as (centre.xyz | left_first), (half-extent.xyz | prim_count), the
@@ -122,7 +123,8 @@ struct SceneDev {
     uint32_t root_leaf; // the root is a leaf: its box is never tested (ex:84), so neither is it by the leaf-box test of the free walks
 };
 
-constexpr uint32_t kStack4Lds = 16; // stack entries of the four-wide traversal kept in LDS (per lane)
+constexpr uint32_t kStack4Lds = 8;  // stack entries of the four-wide traversal kept in LDS per lane (0.3 % of the pushes go deeper: they spill)
+constexpr uint32_t kTileNodesMax = 341; // four-wide nodes staged in LDS by the refill traversal: five full levels (1 + 4 + 16 + 64 + 256), 21.8 KB
 
 struct CameraDev {
     wfpt_gpu_camera cam;

@@ -522,40 +522,63 @@ __device__ __forceinline__ void order2(float &ta, uint32_t &wa, float &tb, uint3
     ta = t0; tb = t1; wa = w0; wb = w1;
 }
 
-// One visit of a (quantised) four-wide node: dequantise the four child boxes (one fma per plane, the arithmetic the host
-// rounded against), test them with the reference's slab arithmetic, and return the children to enter sorted by entry
-// distance (t = 2e30: not entered).
+// One visit of a (quantised) four-wide node. The four child boxes only have to say "maybe" whenever the reference would enter
+// the box they stand for (inner boxes are free, leaf boxes are re-tested exactly: trace_ray_conservative), so a plane distance is
+// ONE fma, (origin + q * scale - o) * inv = q * (scale * inv) + (origin * inv - o * inv), against two per-visit constants per
+// axis, and the sign of inv picks the near / far plane WORD (four children at once) instead of a min / max per plane. The host
+// grew every child box by more than the rounding error of this form before quantising it (collapse_bvh4's margin; same bound
+// as build_nodes_ch). Returns the children to enter sorted by entry distance (t = 2e30: not entered).
 struct Visit4 {
     float t0, t1, t2, t3;
     uint32_t w0, w1, w2, w3;
 };
-__device__ __forceinline__ float ubyte(uint32_t word, int k) { return static_cast<float>((word >> (8 * k)) & 0xffu); }
-__device__ __forceinline__ Visit4 visit4(const float4 *nodes4, uint32_t cur, float ox, float oy, float oz, float ix, float iy, float iz,
-                                         float nearest) {
-    const float4 *nd = nodes4 + 4u * static_cast<size_t>(cur);
-    const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
-    const uint32_t ex = __float_as_uint(a.w);
-    const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23),
-                sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
+struct Ray4 { // per ray: the inverse direction clamped to +-1e30 (no inf - inf for axis-parallel rays) and -(origin * inverse)
+    float bx, by, bz, nox, noy, noz;
+};
+__device__ __forceinline__ Ray4 make_ray4(float ox, float oy, float oz, float ix, float iy, float iz) {
+    Ray4 r;
+    r.bx = min_(max_(ix, -1e30f), 1e30f); r.by = min_(max_(iy, -1e30f), 1e30f); r.bz = min_(max_(iz, -1e30f), 1e30f);
+    r.nox = -(ox * r.bx); r.noy = -(oy * r.by); r.noz = -(oz * r.bz);
+    return r;
+}
+__device__ __forceinline__ float ubyte(uint32_t word, int k) { return static_cast<float>((word >> (8 * k)) & 0xffu); } // v_cvt_f32_ubyteK
+__device__ __forceinline__ Visit4 visit4(const float4 a, const float4 b, const float4 c, const float4 d, const Ray4 &r, float nearest) {
+    // scales: powers of two kept as the upper halves of their floats (Node4::scale_hi)
+    const uint32_t sxy = __float_as_uint(d.z), szw = __float_as_uint(d.w);
+    const float spx = __uint_as_float(sxy << 16) * r.bx, spy = __uint_as_float(sxy & 0xffff0000u) * r.by, spz = __uint_as_float(szw << 16) * r.bz;
+    const float opx = fma_(a.x, r.bx, r.nox), opy = fma_(a.y, r.by, r.noy), opz = fma_(a.z, r.bz, r.noz);
     const uint32_t qlx = __float_as_uint(b.x), qly = __float_as_uint(b.y), qlz = __float_as_uint(b.z), qhx = __float_as_uint(b.w),
                    qhy = __float_as_uint(c.x), qhz = __float_as_uint(c.y);
+    const bool ngx = r.bx < 0.0f, ngy = r.by < 0.0f, ngz = r.bz < 0.0f;
+    const uint32_t nx = ngx ? qhx : qlx, fx = ngx ? qlx : qhx, ny = ngy ? qhy : qly, fy = ngy ? qly : qhy, nz = ngz ? qhz : qlz, fz = ngz ? qlz : qhz;
     Visit4 v;
     v.w0 = __float_as_uint(c.z); v.w1 = __float_as_uint(c.w); v.w2 = __float_as_uint(d.x); v.w3 = __float_as_uint(d.y);
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float4 lo = make_float4(fma_(ubyte(qlx, k), sx, a.x), fma_(ubyte(qly, k), sy, a.y), fma_(ubyte(qlz, k), sz, a.z), 0.0f);
-        const float4 hi = make_float4(fma_(ubyte(qhx, k), sx, a.x), fma_(ubyte(qhy, k), sy, a.y), fma_(ubyte(qhz, k), sz, a.z), 0.0f);
-        t[k] = hit_bvh_node<false>(lo, hi, ox, oy, oz, ix, iy, iz, nearest);
+        const float t_in = max_(max_(fma_(ubyte(nx, k), spx, opx), fma_(ubyte(ny, k), spy, opy)), fma_(ubyte(nz, k), spz, opz));
+        const float t_out = min_(min_(fma_(ubyte(fx, k), spx, opx), fma_(ubyte(fy, k), spy, opy)), fma_(ubyte(fz, k), spz, opz));
+        t[k] = (max_(t_in, 0.0f) <= min_(t_out, nearest)) ? t_in : 2e30f;
     }
-    // a child is entered when the ray meets its box no farther than the nearest hit (hit_bvh_node returns 1e30 otherwise)
-    v.t0 = (v.w0 == kEmptyChild || t[0] >= 1e30f) ? 2e30f : t[0];
-    v.t1 = (v.w1 == kEmptyChild || t[1] >= 1e30f) ? 2e30f : t[1];
-    v.t2 = (v.w2 == kEmptyChild || t[2] >= 1e30f) ? 2e30f : t[2];
-    v.t3 = (v.w3 == kEmptyChild || t[3] >= 1e30f) ? 2e30f : t[3];
+    v.t0 = v.w0 == kEmptyChild ? 2e30f : t[0];
+    v.t1 = v.w1 == kEmptyChild ? 2e30f : t[1];
+    v.t2 = v.w2 == kEmptyChild ? 2e30f : t[2];
+    v.t3 = v.w3 == kEmptyChild ? 2e30f : t[3];
     order2(v.t0, v.w0, v.t1, v.w1); order2(v.t2, v.w2, v.t3, v.w3); order2(v.t0, v.w0, v.t2, v.w2); order2(v.t1, v.w1, v.t3, v.w3);
     order2(v.t1, v.w1, v.t2, v.w2);
     return v;
+}
+// the node's four 16-byte quarters: from the LDS copy of the top of the tree (tile, nodes [0, tile_n)) or from global memory
+__device__ __forceinline__ Visit4 visit4_at(const float4 *nodes4, const float4 *tile, uint32_t tile_n, uint32_t cur, const Ray4 &r, float nearest) {
+    float4 a, b, c, d;
+    if (cur < tile_n) {
+        const float4 *nd = tile + 4u * cur;
+        a = nd[0]; b = nd[1]; c = nd[2]; d = nd[3];
+    } else {
+        const float4 *nd = nodes4 + 4u * static_cast<size_t>(cur);
+        a = nd[0]; b = nd[1]; c = nd[2]; d = nd[3];
+    }
+    return visit4(a, b, c, d, r, nearest);
 }
 
 template <int PRIM>
@@ -563,6 +586,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
                                            float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz;
+    const Ray4 r4 = make_ray4(ox, oy, oz, ix, iy, iz);
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
     uint32_t cur = 0; // node 0 is the root's four-wide node (the root's own box is never tested, ex:84)
@@ -574,7 +598,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
     while (alive) {
         while (alive && !(cur & kLeafFlag)) {
             if (budget-- == 0) { alive = false; break; }
-            const Visit4 v = visit4(nodes4, cur, ox, oy, oz, ix, iy, iz, nearest);
+            const Visit4 v = visit4_at(nodes4, nullptr, 0u, cur, r4, nearest);
             if (v.t0 >= 2e30f) { // nothing to enter
                 if (st.sp == 0) alive = false; else cur = st.pop();
             } else {
@@ -1355,6 +1379,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     uint32_t *s_n = reinterpret_cast<uint32_t *>(lds);   // [kMaxBatch] rays of this wavefront per sample
     uint32_t *s_first = s_n + kMaxBatch;                  // [kMaxBatch + 1] first global ray index of each sample
     uint32_t *s_stack = s_first + kMaxBatch + 4;          // [kStack4Lds][kExtendThreads]
+    const float4 *s_tile = reinterpret_cast<const float4 *>(s_stack + kStack4Lds * kExtendThreads); // [tile_n] nodes: the top of the tree
     const uint32_t n_slots = a.gx * a.gy * 64u;
     if (threadIdx.x < a.batch.n) // the samples' counters, read side by side
         s_n[threadIdx.x] = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[threadIdx.x].shade_n, a.capacity);
@@ -1371,6 +1396,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     const uint32_t total = s_first[a.batch.n];
     if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n) a.ctl[threadIdx.x].n_in = umin(n_slots, a.capacity); // pt:313-316
     if (total == 0) return;
+    // N1: the first tile_n nodes (breadth-first numbering: the top levels of the four-wide tree, where every ray passes) are
+    // staged once per persistent workgroup and read with ds_read_b128; only visits below them go through the L1 / TA path
+    const uint32_t tile_n = a.scene.tile_n;
+    {
+        float4 *tile_w = reinterpret_cast<float4 *>(s_stack + kStack4Lds * kExtendThreads);
+        for (uint32_t i = threadIdx.x; i < 4u * tile_n; i += kExtendThreads) tile_w[i] = a.scene.nodes4[i];
+        __syncthreads();
+    }
     const wfpt_frame_buffer fb0 = a.ctl->frame;
     const uint32_t lane = lane_id();
     Stack4 st;
@@ -1383,6 +1416,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     bool alive = false;
     uint32_t smp = 0, ray = 0, pixel_idx = 0, cur = 0, best = 0xffffffffu, budget = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, aa = 0, nearest = 1e30f;
+    Ray4 r4 = {0, 0, 0, 0, 0, 0};
     bool more = true; // rays left at the cursor (wave-uniform)
     for (;;) {
         // ---------------- refill: idle lanes take the next rays (one atomic per group)
@@ -1425,6 +1459,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 }
                 if (ok) {
                     ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                    r4 = make_ray4(ox, oy, oz, ix, iy, iz);
                     aa = (dx * dx + dy * dy) + dz * dz;
                     nearest = 1e30f; best = 0xffffffffu; cur = 0; st.sp = 0; budget = a.scene.n_nodes;
                     alive = true;
@@ -1447,7 +1482,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             if (budget-- == 0) {
                 fin = true;
             } else {
-            const Visit4 v = visit4(nodes4, cur, ox, oy, oz, ix, iy, iz, nearest);
+            const Visit4 v = visit4_at(nodes4, s_tile, tile_n, cur, r4, nearest);
             if (v.t0 >= 2e30f) {
                 if (st.sp == 0) fin = true; else cur = st.pop();
             } else {
@@ -1740,7 +1775,7 @@ hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream
 }
 
 namespace {
-constexpr uint32_t kRefillLdsBytes = 4u * (2u * kMaxBatch + 4u + kStack4Lds * kExtendThreads);
+constexpr uint32_t kRefillLdsFixed = 4u * (2u * kMaxBatch + 4u + kStack4Lds * kExtendThreads); // + 64 B per staged node
 }
 
 hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s) {
@@ -1748,7 +1783,7 @@ hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream
     using Fn = void (*)(RefillArgs);
     const Fn fn = a.scene.prim_kind == 0 ? (mode == kBounceFirst ? refill_kernel<kBounceFirst, 0> : refill_kernel<kBounceMiddle, 0>)
                                          : (mode == kBounceFirst ? refill_kernel<kBounceFirst, 1> : refill_kernel<kBounceMiddle, 1>);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kExtendThreads), kRefillLdsBytes, s, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kExtendThreads), kRefillLdsFixed + 64u * a.scene.tile_n, s, a);
     return hipGetLastError();
 }
 
