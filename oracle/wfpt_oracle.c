@@ -1108,6 +1108,24 @@ static int model_enter(const float c3[3], const float h3[3], const model_ray *r,
     *t_in = in;
     return orc_max(in, 0.0f) <= orc_min(out, nearest);
 }
+static int model_near_tie(float t, float nearest) { return fabsf(t - nearest) <= nearest * 3.8146973e-6f; }
+/* the candidate distances hit_prim compares with the (0.001, nearest) window, for the model's near-tie watch (spheres only) */
+static int model_sphere_risk(const orc_ctx *c, const orc_ray *ray, uint32_t idx, float nearest) {
+    const orc_sphere *s = &c->spheres[idx];
+    float ocx = ray->origin[0] - s->center[0], ocy = ray->origin[1] - s->center[1], ocz = ray->origin[2] - s->center[2];
+    float dx = ray->direction[0], dy = ray->direction[1], dz = ray->direction[2];
+    float a = (dx * dx + dy * dy) + dz * dz;
+    float b = (dx * ocx + dy * ocy) + dz * ocz;
+    float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s->radius * s->radius;
+    float disc = b * b - a * cc;
+    if (!(disc >= 0.0f)) return 0;
+    float sq = sqrtf(disc);
+    float t = (-b - sq) / a;
+    if (t > 0.001f && model_near_tie(t, nearest)) return 1;
+    if (t > 0.001f && t < nearest) return 0;
+    t = (-b + sq) / a;
+    return t > 0.001f && model_near_tie(t, nearest);
+}
 static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float extent[3], int leaf_exact, orc_hit_payload *hit) {
     model_ray r;
     for (int ax = 0; ax < 3; ax++) {
@@ -1120,14 +1138,25 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
     orc_hit_payload temp;
     memset(&temp, 0, sizeof temp);
     uint32_t stack[ORC_MAX_STACK], sp = 0, node = 0;
+    int risk = 0; /* leaf_exact == 2: near-ties hand the ray to the reference's walk, as the device does */
     for (;;) {
         const orc_bvh_node *nd = &c->nodes[node];
         if (nd->prim_count > 0) {
+            if (leaf_exact == 2 && node != 0) {
+                float tmin = -INFINITY;
+                for (int ax = 0; ax < 3; ax++) {
+                    float t1 = (nd->aabb_min[ax] - ray->origin[ax]) * ray->inv_direction[ax];
+                    float t2 = (nd->aabb_max[ax] - ray->origin[ax]) * ray->inv_direction[ax];
+                    tmin = ax == 0 ? orc_min(t1, t2) : orc_max(orc_min(t1, t2), tmin);
+                }
+                if (model_near_tie(tmin, nearest)) risk = 1;
+            }
             /* the leaf's own box with the reference's arithmetic (the device recomputes it from the primitives; wfpt_create
              * checks that this equals the node's box); the root's box is never tested (ex:84) */
             if (node == 0 || !leaf_exact || !orc_leaf_rejected(nd, ray, nearest)) {
                 for (uint32_t i = 0; i < nd->prim_count; i++) {
                     orc_hit_payload nh;
+                    if (leaf_exact == 2 && !c->triangles && model_sphere_risk(c, ray, nd->left_first + i, nearest)) risk = 1;
                     if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) { nearest = nh.t; temp = nh; }
                 }
             }
@@ -1151,11 +1180,12 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
             node = nd->left_first + (go_right ? 1u : 0u);
         }
     }
+    if (risk) { trace_stat st = {0, 0, 0}; return trace_ray_bvh(c, ray, hit, &st); }
     if (nearest < 1e30f) { *hit = temp; return 1; }
     return 0;
 }
 /* Traces rays 0..n-1 of the ray queue with the reference's traversal and with the model; writes up to max_out records
- * (ray index, kind) of rays whose result differs (leaf_exact = 0: the model WITHOUT the exact test of leaf boxes, i.e. every
+ * (ray index, kind) of rays whose result differs (leaf_exact = 2: the device's walk; 1: without the near-tie hand-over; 0: also WITHOUT the exact test of leaf boxes, i.e. every
  * box merely conservative -- the variant that is NOT equivalent to the reference, kept to show the counter-example): kind 1 = the model reports a hit the reference does not, 2 = the reference
  * reports a hit the model does not, 3 = both hit, different t or primitive. Returns the number of differing rays. */
 uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[3], int leaf_exact, uint32_t *out, uint32_t max_out) {

@@ -12,7 +12,7 @@ from oracle import oracle as O
 
 w, h, frames, bounces = (int(a) for a in (sys.argv[1:5] + ["1920", "1080", "2", "8"][len(sys.argv) - 1:]))
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-LEAF_EXACT = int(sys.argv[6]) if len(sys.argv) > 6 else 1  # 0: every box merely conservative (NOT equivalent: shows the counter-examples)
+LEAF_EXACT = int(sys.argv[6]) if len(sys.argv) > 6 else 2  # 2: the device's walk; 1: no near-tie hand-over; 0: every box merely conservative (1, 0: NOT equivalent)
 O.build()
 L = O.lib()
 L.orc_model_mismatches.restype = C.c_uint32

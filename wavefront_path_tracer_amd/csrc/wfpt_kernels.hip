@@ -277,9 +277,15 @@ struct Traversal {
 // Primitive tests. PRIM 0: hit(), ex:185-210 (sphere, half-b quadratic, both roots against the window).
 // PRIM 1 (build extension, no reference code): Moeller-Trumbore in a fixed evaluation order; a degenerate
 // triangle gives inf/NaN barycentrics and fails the negated range tests.
-template <int PRIM>
+// Two candidate distances within 2^-18 of each other (relative): which of them the reference reports can hinge on the ORDER in
+// which its walk meets them (the first of two bit-equal hits wins, ex:190-207's strict `<`; a box whose entry distance lies a
+// rounding error beyond a hit inside it is skipped or not depending on what was found before). The walks that are free in
+// their visit order (trace_ray_conservative, trace_ray4) watch for this and hand such a ray to the reference's own walk.
+__device__ __forceinline__ bool near_tie(float t, float nearest) { return __builtin_fabsf(t - nearest) <= nearest * 3.8146973e-6f; }
+
+template <int PRIM, bool TRACK = false>
 __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float ox, float oy, float oz, float dx, float dy,
-                                         float dz, float a, float &nearest, uint32_t &best) {
+                                         float dz, float a, float &nearest, uint32_t &best, bool *risk = nullptr) {
     if (PRIM == 0) {
         const float4 s = geom[idx];
         const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
@@ -289,11 +295,13 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
         if (discrim >= 0.0f) {
             const float sq = sqrt_(discrim);
             float t = (-b - sq) / a;
+            if (TRACK && t > 0.001f && near_tie(t, nearest)) *risk = true;
             if (t > 0.001f && t < nearest) {
                 nearest = t;
                 best = idx;
             } else {
                 t = (-b + sq) / a;
+                if (TRACK && t > 0.001f && near_tie(t, nearest)) *risk = true;
                 if (t > 0.001f && t < nearest) {
                     nearest = t;
                     best = idx;
@@ -312,6 +320,7 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
             const float v = ((dx * qx + dy * qy) + dz * qz) * inv_det;
             if (v >= 0.0f && u + v <= 1.0f) {
                 const float t = ((e2.x * qx + e2.y * qy) + e2.z * qz) * inv_det;
+                if (TRACK && t > 0.001f && near_tie(t, nearest)) *risk = true;
                 if (t > 0.001f && t < nearest) {
                     nearest = t;
                     best = idx;
@@ -342,11 +351,12 @@ __device__ __forceinline__ void grow_prim_box(const float4 *geom, uint32_t idx, 
 // trace_ray_conservative for why that makes the set of tested primitives exactly the reference's.
 template <int PRIM>
 __device__ __forceinline__ bool leaf_box_passes(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float ix,
-                                                float iy, float iz, float nearest) {
+                                                float iy, float iz, float nearest, bool &risk) {
     float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
     float tmin, tmax;
     slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
+    if (near_tie(tmin, nearest)) risk = true; // `tmin > nearest` decided by a rounding error: see near_tie
     return !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
 }
 
@@ -438,7 +448,7 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
 template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
                                                        float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
-                                                       uint32_t &prim_out) {
+                                                       uint32_t &prim_out, bool &risk) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz; // dot(direction, direction), ex:190
     const float bx = min_(max_(ix, -1e30f), 1e30f), by = min_(max_(iy, -1e30f), 1e30f), bz = min_(max_(iz, -1e30f), 1e30f);
@@ -481,9 +491,9 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf (ex:86-103); the root's own box is never tested (ex:84)
-            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest))
+            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest, risk))
                 for (uint32_t i = 0; i < tr.prim_count; ++i)
-                    hit_prim<PRIM>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+                    hit_prim<PRIM, true>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best, &risk);
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
@@ -501,17 +511,18 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
 // column, spilling to global memory past kStack4Lds entries).
 struct Stack4 {
     uint32_t *lds;    // this lane's LDS column: entry k at lds[k * kExtendThreads]
-    uint32_t *spill;  // this thread's global column: entry k (>= kStack4Lds) at spill[(k - kStack4Lds) * stride]
-    uint32_t stride;
+    uint32_t *spill;  // the spill area (uniform): entry k (>= kStack4Lds) of global thread `col` at spill[(k - kStack4Lds) * stride + col]
+    uint32_t stride;  // (uniform)
+    uint32_t col;     // this thread's column in the spill area
     uint32_t sp = 0;
     __device__ __forceinline__ void push(uint32_t w) {
         if (sp < kStack4Lds) lds[sp * kExtendThreads] = w;
-        else spill[static_cast<size_t>(sp - kStack4Lds) * stride] = w;
+        else spill[static_cast<size_t>(sp - kStack4Lds) * stride + col] = w;
         sp += 1;
     }
     __device__ __forceinline__ uint32_t pop() {
         sp -= 1;
-        return sp < kStack4Lds ? lds[sp * kExtendThreads] : spill[static_cast<size_t>(sp - kStack4Lds) * stride];
+        return sp < kStack4Lds ? lds[sp * kExtendThreads] : spill[static_cast<size_t>(sp - kStack4Lds) * stride + col];
     }
 };
 
@@ -524,7 +535,7 @@ __device__ __forceinline__ void order2(float &ta, uint32_t &wa, float &tb, uint3
 
 // One visit of a (quantised) four-wide node. The four child boxes only have to say "maybe" whenever the reference would enter
 // the box they stand for (inner boxes are free, leaf boxes are re-tested exactly: trace_ray_conservative), so a plane distance is
-// ONE fma, (origin + q * scale - o) * inv = q * (scale * inv) + (origin * inv - o * inv), against two per-visit constants per
+// ONE fma, (origin + q * scale - o) * inv = q * (scale * inv) + (origin - o) * inv, against two per-visit constants per
 // axis, and the sign of inv picks the near / far plane WORD (four children at once) instead of a min / max per plane. The host
 // grew every child box by more than the rounding error of this form before quantising it (collapse_bvh4's margin; same bound
 // as build_nodes_ch). Returns the children to enter sorted by entry distance (t = 2e30: not entered).
@@ -532,13 +543,13 @@ struct Visit4 {
     float t0, t1, t2, t3;
     uint32_t w0, w1, w2, w3;
 };
-struct Ray4 { // per ray: the inverse direction clamped to +-1e30 (no inf - inf for axis-parallel rays) and -(origin * inverse)
-    float bx, by, bz, nox, noy, noz;
+struct Ray4 { // per ray: the origin and the inverse direction clamped to +-1e30 (no inf - inf for axis-parallel rays)
+    float ox, oy, oz, bx, by, bz;
 };
-__device__ __forceinline__ Ray4 make_ray4(float ox, float oy, float oz, float ix, float iy, float iz) {
+__device__ __forceinline__ Ray4 make_ray4(float ox, float oy, float oz, float dx, float dy, float dz) {
     Ray4 r;
-    r.bx = min_(max_(ix, -1e30f), 1e30f); r.by = min_(max_(iy, -1e30f), 1e30f); r.bz = min_(max_(iz, -1e30f), 1e30f);
-    r.nox = -(ox * r.bx); r.noy = -(oy * r.by); r.noz = -(oz * r.bz);
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.bx = min_(max_(1.0f / dx, -1e30f), 1e30f); r.by = min_(max_(1.0f / dy, -1e30f), 1e30f); r.bz = min_(max_(1.0f / dz, -1e30f), 1e30f);
     return r;
 }
 __device__ __forceinline__ float ubyte(uint32_t word, int k) { return static_cast<float>((word >> (8 * k)) & 0xffu); } // v_cvt_f32_ubyteK
@@ -546,7 +557,7 @@ __device__ __forceinline__ Visit4 visit4(const float4 a, const float4 b, const f
     // scales: powers of two kept as the upper halves of their floats (Node4::scale_hi)
     const uint32_t sxy = __float_as_uint(d.z), szw = __float_as_uint(d.w);
     const float spx = __uint_as_float(sxy << 16) * r.bx, spy = __uint_as_float(sxy & 0xffff0000u) * r.by, spz = __uint_as_float(szw << 16) * r.bz;
-    const float opx = fma_(a.x, r.bx, r.nox), opy = fma_(a.y, r.by, r.noy), opz = fma_(a.z, r.bz, r.noz);
+    const float opx = (a.x - r.ox) * r.bx, opy = (a.y - r.oy) * r.by, opz = (a.z - r.oz) * r.bz; // (keeps three registers fewer per lane than a pre-multiplied origin)
     const uint32_t qlx = __float_as_uint(b.x), qly = __float_as_uint(b.y), qlz = __float_as_uint(b.z), qhx = __float_as_uint(b.w),
                    qhy = __float_as_uint(c.x), qhz = __float_as_uint(c.y);
     const bool ngx = r.bx < 0.0f, ngy = r.by < 0.0f, ngz = r.bz < 0.0f;
@@ -583,10 +594,10 @@ __device__ __forceinline__ Visit4 visit4_at(const float4 *nodes4, const float4 *
 
 template <int PRIM>
 __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *prim_geom, Stack4 st, float ox, float oy, float oz, float dx,
-                                           float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out) {
+                                           float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out, bool &risk) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz;
-    const Ray4 r4 = make_ray4(ox, oy, oz, ix, iy, iz);
+    const Ray4 r4 = make_ray4(ox, oy, oz, dx, dy, dz);
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
     uint32_t cur = 0; // node 0 is the root's four-wide node (the root's own box is never tested, ex:84)
@@ -613,9 +624,9 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
             // the quantised boxes above are LARGER than the caller's: the leaf's own box decides, with the reference's arithmetic
             // (see trace_ray_conservative), whether its primitives are tested
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest))
+            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest, risk))
                 for (uint32_t i = 0; i < count; ++i)
-                    hit_prim<PRIM>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+                    hit_prim<PRIM, true>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best, &risk);
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
     }
@@ -706,14 +717,22 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
             if (LDS_SCENE && EXACT)
                 hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
                                                                 prim);
-            else if (LDS_SCENE)
-                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
-            else if (!EXACT && a.scene.nodes4) {
+            else if (LDS_SCENE) {
+                bool risk = false;
+                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
+                if (risk) // a near-tie: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                    hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(g_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
                 st.lds = s_stack + threadIdx.x;
                 st.stride = a.scene.spill_stride;
-                st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
-                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
+                st.spill = a.scene.stack_spill;
+                st.col = blockIdx.x * kExtendThreads + threadIdx.x;
+                bool risk = false;
+                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
+                if (risk)
+                    hit = trace_ray<Trail, PRIM, uint32_t, 0, true>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, nullptr, ox, oy, oz, dx, dy, dz,
+                                                                     a.scene.n_nodes, t, prim);
             } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
                                                                             s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
@@ -1317,14 +1336,22 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         if (live) {
             if (LDS_SCENE && EXACT)
                 hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
-            else if (LDS_SCENE)
-                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
-            else if (!EXACT && a.scene.nodes4) {
+            else if (LDS_SCENE) {
+                bool risk = false;
+                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
+                if (risk) // a near-tie: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                    hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(g_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
                 st.lds = L.stack + threadIdx.x;
                 st.stride = a.scene.spill_stride;
-                st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
-                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
+                st.spill = a.scene.stack_spill;
+                st.col = blockIdx.x * kExtendThreads + threadIdx.x;
+                bool risk = false;
+                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
+                if (risk)
+                    hit = trace_ray<Trail, PRIM, uint32_t, 0, true>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, nullptr, ox, oy, oz, dx, dy, dz,
+                                                                     a.scene.n_nodes, t, prim);
             } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
                                                                             ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
@@ -1409,14 +1436,18 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     Stack4 st;
     st.lds = s_stack + threadIdx.x;
     st.stride = a.scene.spill_stride;
-    st.spill = a.scene.stack_spill + (static_cast<size_t>(blockIdx.x) * kExtendThreads + threadIdx.x);
+    st.spill = a.scene.stack_spill;
+    st.col = blockIdx.x * kExtendThreads + threadIdx.x;
     const float4 *nodes4 = a.scene.nodes4;
 
     // per-lane ray and traversal state
     bool alive = false;
     uint32_t smp = 0, ray = 0, pixel_idx = 0, cur = 0, best = 0xffffffffu, budget = 0;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, aa = 0, nearest = 1e30f;
+    // (the exact inverse direction and d.d are needed at leaves only, ~2 per ray against ~60 node visits: recomputed there, which
+    // keeps the hot loop's registers free of them; more state here meant scratch spills inside the loop)
+    float dx = 0, dy = 0, dz = 0, nearest = 1e30f;
     Ray4 r4 = {0, 0, 0, 0, 0, 0};
+    bool risk = false; // this lane's ray met a near-tie (near_tie): the reference's own walk re-traces it when it ends
     bool more = true; // rays left at the cursor (wave-uniform)
     for (;;) {
         // ---------------- refill: idle lanes take the next rays (one atomic per group)
@@ -1436,6 +1467,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 wfpt_frame_buffer fb = fb0;
                 fb.frame += smp;
                 bool ok = true;
+                float ox = 0, oy = 0, oz = 0;
                 if (MODE == kBounceFirst) { // generate_rays (gr:42-91), true-size semantics
                     const uint32_t workgroup_index = ray >> 6, local_index = ray & 63u;
                     const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
@@ -1458,11 +1490,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                     shade_hit<true>(src, ray, s_n[smp], fb, ox, oy, oz, dx, dy, dz, pixel_idx);
                 }
                 if (ok) {
-                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
-                    r4 = make_ray4(ox, oy, oz, ix, iy, iz);
-                    aa = (dx * dx + dy * dy) + dz * dz;
+                    r4 = make_ray4(ox, oy, oz, dx, dy, dz);
                     nearest = 1e30f; best = 0xffffffffu; cur = 0; st.sp = 0; budget = a.scene.n_nodes;
                     alive = true;
+                    risk = false;
                 }
             }
         }
@@ -1498,16 +1529,22 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 fin = true;
             } else {
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest)) // see trace_ray4
+                const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
+                const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
+                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, ix, iy, iz, nearest, risk)) // see trace_ray4
                     for (uint32_t i = 0; i < count; ++i)
-                        hit_prim<PRIM>(a.scene.prim_geom, first + i, ox, oy, oz, dx, dy, dz, aa, nearest, best);
+                        hit_prim<PRIM, true>(a.scene.prim_geom, first + i, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best, &risk);
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
         if (alive && fin) { // the ray is done: dense record in ray order (p = o + t d as shade reads it, sh:91)
+            if (risk) // rare: the reference's own walk over the caller's binary tree decides
+                (void)trace_ray<unsigned long long, PRIM, uint32_t, 0, true>(reinterpret_cast<const float4 *>(a.scene.nodes), a.scene.prim_geom,
+                                                                              a.scene.pair_parent32, nullptr, r4.ox, r4.oy, r4.oz, dx, dy, dz,
+                                                                              a.scene.n_nodes, nearest, best);
             const size_t slot = smp * a.batch.queue_stride + ray;
             const bool hit = nearest < 1e30f; // ex:157
-            a.dense_out[2u * slot] = make_float4(ox + nearest * dx, oy + nearest * dy, oz + nearest * dz, __uint_as_float(pixel_idx));
+            a.dense_out[2u * slot] = make_float4(r4.ox + nearest * dx, r4.oy + nearest * dy, r4.oz + nearest * dz, __uint_as_float(pixel_idx));
             a.dense_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(hit ? best : kDenseMiss));
             alive = false;
         }
