@@ -1074,17 +1074,18 @@ void orc_sim_postpone(orc_ctx *c, uint32_t n, uint32_t Q, uint64_t out[8]) {
  * so that the hunt for rays on which a conservative box test could change the reported hit runs on the CPU, over millions of
  * rays, without a GPU. Not part of the oracle proper: the reference's traversal is trace_ray_bvh above. Same arithmetic as the
  * device (fmaf = one fused multiply-add, -ffp-contract=off elsewhere): node boxes as centre / half-extent, the half-extent grown
- * by 2^-19 * extent per axis; per axis tc = fma(c, b, -(o b)), entry = fma(h, -|b|, tc), exit = fma(h, |b|, tc);
+ * by 2^-17 * extent per axis (extent[0..2]; extent[3..5] = centre and extent[6] = squared radius of the ball of origins the
+ * free walk is used for, wfpt_api.hip: safe_region); per axis tc = fma(c, b, -(o b)), entry = fma(h, -|b|, tc), exit = fma(h, |b|, tc);
  * entered <=> max(entry, 0) <= min(exit, nearest). */
 #include <math.h>
 static float model_up(double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, INFINITY); return f; }
-static void model_box(const orc_bvh_node *nd, const float extent[3], float c3[3], float h3[3]) {
+static void model_box(const orc_bvh_node *nd, const float extent[7], float c3[3], float h3[3]) {
     for (int ax = 0; ax < 3; ax++) {
         double lo = nd->aabb_min[ax], hi = nd->aabb_max[ax];
         float c = (float)(0.5 * (lo + hi));
         double h = fmax((double)c - lo, hi - (double)c);
         c3[ax] = c;
-        h3[ax] = model_up((double)model_up(h) + ldexp((double)extent[ax], -19));
+        h3[ax] = model_up((double)model_up(h) + ldexp((double)extent[ax], -17));
     }
 }
 static int orc_leaf_rejected(const orc_bvh_node *node, const orc_ray *ray, float nearest_hit) { /* ex:165-179 as a boolean */
@@ -1126,7 +1127,7 @@ static int model_sphere_risk(const orc_ctx *c, const orc_ray *ray, uint32_t idx,
     t = (-b + sq) / a;
     return t > 0.001f && model_near_tie(t, nearest);
 }
-static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float extent[3], int leaf_exact, orc_hit_payload *hit) {
+static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float extent[7], int leaf_exact, orc_hit_payload *hit) {
     model_ray r;
     for (int ax = 0; ax < 3; ax++) {
         float inv = 1.0f / ray->direction[ax];
@@ -1138,7 +1139,11 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
     orc_hit_payload temp;
     memset(&temp, 0, sizeof temp);
     uint32_t stack[ORC_MAX_STACK], sp = 0, node = 0;
-    int risk = 0; /* leaf_exact == 2: near-ties hand the ray to the reference's walk, as the device does */
+    int risk = 0; /* leaf_exact == 2: near-ties, probes and far origins hand the ray to the reference's walk, as the device does */
+    if (leaf_exact == 2) {
+        float fx = ray->origin[0] - extent[3], fy = ray->origin[1] - extent[4], fz = ray->origin[2] - extent[5];
+        if ((fx * fx + fy * fy) + fz * fz > extent[6]) { trace_stat st0 = {0, 0, 0}; return trace_ray_bvh(c, ray, hit, &st0); }
+    }
     for (;;) {
         const orc_bvh_node *nd = &c->nodes[node];
         if (nd->prim_count > 0) {
@@ -1158,6 +1163,11 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
                     orc_hit_payload nh;
                     if (leaf_exact == 2 && !c->triangles && model_sphere_risk(c, ray, nd->left_first + i, nearest)) risk = 1;
                     if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) { nearest = nh.t; temp = nh; }
+                }
+            } else if (leaf_exact == 2) { /* probe_leaf: a primitive of a leaf whose box fails would be accepted */
+                for (uint32_t i = 0; i < nd->prim_count; i++) {
+                    orc_hit_payload nh;
+                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) risk = 1;
                 }
             }
             if (sp == 0) break;
@@ -1188,7 +1198,7 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
  * (ray index, kind) of rays whose result differs (leaf_exact = 2: the device's walk; 1: without the near-tie hand-over; 0: also WITHOUT the exact test of leaf boxes, i.e. every
  * box merely conservative -- the variant that is NOT equivalent to the reference, kept to show the counter-example): kind 1 = the model reports a hit the reference does not, 2 = the reference
  * reports a hit the model does not, 3 = both hit, different t or primitive. Returns the number of differing rays. */
-uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[3], int leaf_exact, uint32_t *out, uint32_t max_out) {
+uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[7], int leaf_exact, uint32_t *out, uint32_t max_out) {
     uint32_t count = 0;
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int64_t idx = 0; idx < (int64_t)n; idx++) {

@@ -150,7 +150,7 @@ void     orc_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_sample
 int      orc_num_threads(void);
 
 /* model of the DEVICE's conservative traversal vs the reference's, over the ray queue (see wfpt_oracle.c) */
-uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[3], int leaf_exact, uint32_t *out, uint32_t max_out);
+uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[7], int leaf_exact, uint32_t *out, uint32_t max_out);
 
 #ifdef __cplusplus
 }

@@ -11,11 +11,24 @@ import numpy as np
 import pytest
 
 
-def _extent(O, nodes, cam):
+def _extent(O, nodes, cam, spheres=None):
+    """[extent x, y, z, safe centre x, y, z, safe radius^2]: what wfpt_api.hip computes for the device (scene_extent, safe_region)."""
     reach = np.abs(cam["position"][0][:3]) + max(float(cam["defocus_radius"][0]), 0.0)
     keep = [i for i in range(len(nodes)) if i != 1]
-    return np.maximum(0.25 * reach, np.maximum(np.abs(nodes["aabb_min"][keep]).max(axis=0),
-                                               np.abs(nodes["aabb_max"][keep]).max(axis=0))).astype("<f4")
+    ext = np.maximum(0.25 * reach, np.maximum(np.abs(nodes["aabb_min"][keep]).max(axis=0),
+                                             np.abs(nodes["aabb_max"][keep]).max(axis=0))).astype("<f4")
+    if spheres is None:
+        return np.concatenate([ext, np.zeros(3, "<f4"), np.float32([np.inf])]).astype("<f4")
+    c = spheres["center"][:, :3].astype(np.float64)
+    r = np.abs(spheres["radius"].astype(np.float64))
+    big = int(np.argmax(r))
+    rest = np.delete(c, big, axis=0) if len(c) > 1 else c
+    centre = (0.5 * (rest.min(axis=0) + rest.max(axis=0))).astype("<f4")
+    margin = 0.875 * float(ext.min()) * 2.0 ** -17
+    d_safe = np.sqrt(margin * r / (6.0 * 2.0 ** -24))
+    radius = float((d_safe - np.linalg.norm(c - centre.astype(np.float64), axis=1)).min())
+    r2 = np.float32(radius * radius) if radius > 0 else np.float32(-1.0)
+    return np.concatenate([ext, centre, [r2]]).astype("<f4")
 
 
 def _mismatches(O, o, n, extent, leaf_exact):
@@ -33,9 +46,9 @@ def test_model_of_the_device_walk_equals_the_reference_walk(orc, seed):
     w, h, bounces = 400, 224, 6
     o = O.shirley_oracle(w, h, seed=seed, max_wavefronts=bounces)
     sp, _ = O.scene_book_one_final(seed)
-    _, nodes = O.build_bvh(sp)
+    sp, nodes = O.build_bvh(sp)
     cam, _, _ = O.shirley_camera(w, h)
-    extent = _extent(O, nodes, cam)
+    extent = _extent(O, nodes, cam, sp)
     compared = 0
     for frame in (1, 2, 3):
         n = w * h
@@ -68,9 +81,9 @@ def test_counter_example_every_box_conservative_is_not_the_reference(orc):
     w, h = 1920, 1080
     o = O.shirley_oracle(w, h, seed=1, max_wavefronts=8)
     sp, _ = O.scene_book_one_final(1)
-    _, nodes = O.build_bvh(sp)
+    sp, nodes = O.build_bvh(sp)
     cam, _, _ = O.shirley_camera(w, h)
-    extent = _extent(O, nodes, cam)
+    extent = _extent(O, nodes, cam, sp)
     n = w * h
     o.set_frame(18, 0); o.reset_image(); o.set_counters([0, 0, n])
     o.generate_rays(w // 8, h // 8, True)
@@ -103,9 +116,9 @@ def test_counter_example_visit_order_decides_a_tie(orc):
     w, h, bounces = 3840, 2160, 4
     o = O.shirley_oracle(w, h, seed=1, max_wavefronts=bounces)
     sp, _ = O.scene_book_one_final(1)
-    _, nodes = O.build_bvh(sp)
+    sp, nodes = O.build_bvh(sp)
     cam, _, _ = O.shirley_camera(w, h)
-    extent = _extent(O, nodes, cam)
+    extent = _extent(O, nodes, cam, sp)
     n = w * h
     o.set_frame(7, 0); o.reset_image(); o.set_counters([0, 0, n])
     o.generate_rays(w // 8, h // 8, True)

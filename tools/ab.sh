@@ -5,7 +5,7 @@ tag=$1; shift
 for lib in wavefront_path_tracer_amd/libwfpt.so build/libwfpt_*.so; do
   [ -f "$lib" ] || continue
   name=$(basename $lib .so | sed 's/libwfpt_\?//'); [ -z "$name" ] && name=default
-  WFPT_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps 64 --warmup 4 --no-cpu-baseline "$@" > gpurun_out/ab_${tag}_${name}.json 2> gpurun_out/ab_${tag}_${name}.err || { echo "$name FAILED"; tail -3 gpurun_out/ab_${tag}_${name}.err; continue; }
+  WFPT_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/ab_${tag}_${name}.json 2> gpurun_out/ab_${tag}_${name}.err || { echo "$name FAILED"; tail -3 gpurun_out/ab_${tag}_${name}.err; continue; }
   python - "$name" gpurun_out/ab_${tag}_${name}.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[2]))

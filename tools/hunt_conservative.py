@@ -21,10 +21,10 @@ o = O.shirley_oracle(w, h, seed=seed, max_wavefronts=bounces)
 sp, mt = O.scene_book_one_final(seed)
 sp, nodes = O.build_bvh(sp)
 cam, _, _ = O.shirley_camera(w, h)
-reach = np.abs(cam["position"][0][:3]) + max(float(cam["defocus_radius"][0]), 0.0)
-extent = np.maximum(0.25 * reach, np.maximum(np.abs(nodes["aabb_min"][[i for i in range(len(nodes)) if i != 1]]).max(axis=0),
-                                             np.abs(nodes["aabb_max"][[i for i in range(len(nodes)) if i != 1]]).max(axis=0))).astype("<f4")
-print("extent", extent, "margin", extent * 2.0 ** -19)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from test_traversal_model import _extent
+extent = _extent(O, nodes, cam, sp)
+print("extent", extent[:3], "margin", extent[:3] * 2.0 ** -17, "safe ball: centre", extent[3:6], "radius", float(np.sqrt(max(extent[6], 0))))
 out = np.zeros((4096, 2), "<u4")
 total = 0
 for frame in range(1, frames + 1):

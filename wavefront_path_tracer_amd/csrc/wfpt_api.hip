@@ -557,6 +557,16 @@ int stage_end(wfpt_ctx *c, int stage) {
 // |o| <= 4 extent, |c|, h <= extent: less than half of margin * |b|. So the computed entry distance never exceeds the
 // exact box's and the computed exit distance never falls below it: the test can only say "enter" more often than the
 // reference's (ex:164-183), never less. Returns false (=> the exact test is used) when a box is not finite.
+// Inner boxes of the free walks are grown by margin = 2^kMarginLog2 * extent per axis. The margin pays for two things:
+//  (a) the rounding error of the one-fma plane distances, < 2^-20 * extent (build_nodes_ch), and
+//  (b) the rounding slack of the PRIMITIVE test: the reference's sphere test (ex:185-210) accepts a ray that passes up to
+//      about 6 * 2^-24 * D^2 / r outside a sphere of radius r whose centre is D away from the ray's origin (its discriminant
+//      b^2 - a c cancels ~12 * 2^-24 * a |o - c|^2). Such a "hit" is the reference's hit whenever the reference tests the
+//      primitive -- through a leaf box that passes, or blindly (probe_leaf) -- so the free walk must at least REACH every
+//      leaf the ray passes that close to: margin >= slack, i.e. D <= sqrt(margin * r / (6 * 2^-24)). safe_region() turns this
+//      into one ball of origins per scene; rays from outside it are traced by the reference's own walk (far_origin).
+constexpr int kMarginLog2 = -17;
+
 // per axis: a bound on every |coordinate| of the scene and on a quarter of the camera's reach; false if a box is not finite
 bool scene_extent(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float cam_reach[3], float extent[3]) {
     for (int ax = 0; ax < 3; ++ax) {
@@ -587,7 +597,7 @@ bool build_nodes_ch(const wfpt_bvh_node *nodes, uint32_t n_nodes, const float ca
             const float c = static_cast<float>(0.5 * (lo + hi));
             const double h = std::max(static_cast<double>(c) - lo, hi - static_cast<double>(c)); // exact in double
             c3[ax] = c;
-            h3[ax] = up(static_cast<double>(up(h)) + std::ldexp(static_cast<double>(extent[ax]), -19));
+            h3[ax] = up(static_cast<double>(up(h)) + std::ldexp(static_cast<double>(extent[ax]), kMarginLog2));
         }
         float lf, pc;
         std::memcpy(&lf, &nodes[i].left_first, 4);
@@ -635,6 +645,37 @@ bool tree_is_recomputable(const wfpt_bvh_node *nodes, uint32_t n_nodes, const wf
         }
     }
     return true;
+}
+
+// The ball of ray origins for which every sphere's test slack stays within 7/8 of the smallest margin (1/8 is the plane
+// distances' own rounding): centre = the middle of the box of all sphere centres but the largest sphere's, radius = the minimum
+// over spheres of D_safe(r) - |centre - c|. Triangles (build extension): no closed bound is claimed, the region is unbounded.
+void safe_region(const wfpt_sphere *spheres, uint32_t n, const float extent[3], float centre[3], float *r2) {
+    centre[0] = centre[1] = centre[2] = 0.0f;
+    *r2 = INFINITY;
+    if (!spheres || n == 0) return;
+    uint32_t biggest = 0;
+    for (uint32_t i = 1; i < n; ++i)
+        if (spheres[i].radius > spheres[biggest].radius) biggest = i;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i == biggest && n > 1) continue;
+        for (int ax = 0; ax < 3; ++ax) {
+            lo[ax] = std::min(lo[ax], static_cast<double>(spheres[i].center[ax]));
+            hi[ax] = std::max(hi[ax], static_cast<double>(spheres[i].center[ax]));
+        }
+    }
+    for (int ax = 0; ax < 3; ++ax) centre[ax] = static_cast<float>(0.5 * (lo[ax] + hi[ax]));
+    const double margin = 0.875 * std::ldexp(static_cast<double>(std::min(extent[0], std::min(extent[1], extent[2]))), kMarginLog2);
+    double radius = INFINITY;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double r = std::fabs(static_cast<double>(spheres[i].radius));
+        const double d_safe = std::sqrt(margin * r / (6.0 * std::ldexp(1.0, -24)));
+        double dist2 = 0.0;
+        for (int ax = 0; ax < 3; ++ax) dist2 += (spheres[i].center[ax] - centre[ax]) * (spheres[i].center[ax] - centre[ax]);
+        radius = std::min(radius, d_safe - std::sqrt(dist2));
+    }
+    *r2 = radius > 0.0 ? static_cast<float>(radius * radius) : -1.0f; // -1: no origin is safe, every ray takes the reference's walk
 }
 
 // ray origins the camera can produce: |position| + the lens radius (gr:73-79), per axis
@@ -747,7 +788,7 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
         std::vector<Node4> n4;
         float margin[3];
         if (scene_extent(nodes, n_nodes, reach, c->extent)) {
-            for (int ax = 0; ax < 3; ++ax) margin[ax] = std::nextafterf(std::ldexp(c->extent[ax], -19), INFINITY);
+            for (int ax = 0; ax < 3; ++ax) margin[ax] = std::nextafterf(std::ldexp(c->extent[ax], kMarginLog2), INFINITY);
             if (collapse_bvh4(nodes, n_nodes, margin, n4, c->depth4)) {
                 WFPT_HIP(c, dmalloc(&c->d_nodes4, 4 * n4.size()));
                 WFPT_HIP(c, hipMemcpy(c->d_nodes4, n4.data(), sizeof(Node4) * n4.size(), hipMemcpyHostToDevice));
@@ -777,6 +818,7 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
     c->scene.lds_bytes = extend_lds_bytes(n_nodes, n_spheres, prim_kind, lds_scene);
     c->scene.depth = bvh_depth;
     c->scene.root_leaf = nodes[0].prim_count > 0 ? 1u : 0u;
+    safe_region(spheres, n_spheres, c->extent, c->scene.safe_c, &c->scene.safe_r2);
     c->far_rays = false;
     decide_exact(c, reach);
 

@@ -119,6 +119,7 @@ struct SceneDev {
     // LDS-resident scenes, default traversal: every node as (centre.xyz | left_first), (half-extent.xyz | prim_count), the
     // half-extent grown by more than the box test's rounding error (trace_ray_conservative); staged instead of `nodes`
     const float4 *nodes_ch;
+    float safe_c[3], safe_r2; // free walks: origins within sqrt(safe_r2) of safe_c are covered by the margin's bound (far_origin)
     uint32_t exact; // 1: WFPT_FLAG_EXACT_TRAVERSAL (or a fallback to it): the reference's box test and 1e30 miss value
     uint32_t root_leaf; // the root is a leaf: its box is never tested (ex:84), so neither is it by the leaf-box test of the free walks
 };

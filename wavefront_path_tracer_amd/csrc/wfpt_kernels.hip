@@ -25,6 +25,21 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long mask) {
 }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+// Pointers with their address space in the TYPE, for code that picks per lane between an LDS copy and global memory: hipcc
+// otherwise folds `if (in_lds) x = lds[i]; else x = global[j];` into a select of two generic pointers and ONE flat load, which
+// occupies both the LDS and the vector-memory path every time. Loads through these types cannot be merged.
+#define WFPT_AS_LDS __attribute__((address_space(3)))
+#define WFPT_AS_GLOBAL __attribute__((address_space(1)))
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load4_lds(const float4 *p) {
+    const v4f_ v = *(const WFPT_AS_LDS v4f_ *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 load4_global(const float4 *p) {
+    const v4f_ v = *(const WFPT_AS_GLOBAL v4f_ *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // pixel index -> slot in this context's image slab (identity unless the image is sharded by bands)
 __device__ __forceinline__ uint32_t local_pixel(uint32_t pixel, uint32_t width, Tiling tile) {
     if (tile.world <= 1) return pixel;
@@ -192,6 +207,14 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
     return (tmin > tmax || tmax <= 0.0f || tmin > nearest) ? (EXACT ? 1e30f : kBoxMiss) : tmin;
 }
 
+// measurement-only switches (tools/build_variant.sh): what each safety layer of the free walks costs. NOT for use: without them
+// the walks are no longer equivalent to the reference's (tests/test_traversal_model.py holds the counter-examples).
+#ifndef WFPT_EXP_NO_TIE
+#define WFPT_EXP_NO_TIE 0     // 1: no near-tie watch, no probe of failed leaves, no far-origin hand-over
+#endif
+#ifndef WFPT_EXP_NO_LEAFBOX
+#define WFPT_EXP_NO_LEAFBOX 0 // 1: leaf boxes are not re-tested with the reference's arithmetic
+#endif
 #ifndef WFPT_BUDGET_INNER
 #define WFPT_BUDGET_INNER 0 // 1: count the step budget down on every inner visit as well (costs 3 instructions per visit)
 #endif
@@ -281,7 +304,7 @@ struct Traversal {
 // which its walk meets them (the first of two bit-equal hits wins, ex:190-207's strict `<`; a box whose entry distance lies a
 // rounding error beyond a hit inside it is skipped or not depending on what was found before). The walks that are free in
 // their visit order (trace_ray_conservative, trace_ray4) watch for this and hand such a ray to the reference's own walk.
-__device__ __forceinline__ bool near_tie(float t, float nearest) { return __builtin_fabsf(t - nearest) <= nearest * 3.8146973e-6f; }
+__device__ __forceinline__ bool near_tie(float t, float nearest) { return !WFPT_EXP_NO_TIE && __builtin_fabsf(t - nearest) <= nearest * 3.8146973e-6f; }
 
 template <int PRIM, bool TRACK = false>
 __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float ox, float oy, float oz, float dx, float dy,
@@ -352,12 +375,38 @@ __device__ __forceinline__ void grow_prim_box(const float4 *geom, uint32_t idx, 
 template <int PRIM>
 __device__ __forceinline__ bool leaf_box_passes(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float ix,
                                                 float iy, float iz, float nearest, bool &risk) {
+    if (WFPT_EXP_NO_LEAFBOX) return true;
     float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
     float tmin, tmax;
     slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
     if (near_tie(tmin, nearest)) risk = true; // `tmin > nearest` decided by a rounding error: see near_tie
     return !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
+}
+
+// A leaf the free walk has reached but whose own box FAILS the reference's test. The reference does not test its primitives on
+// that account -- but it may test them all the same: while nothing is hit yet, a pair of boxes the ray misses both of is still
+// entered, left child first (ex:124, `1e30 > 1e30`), down to the leftmost leaf below, whose primitives are then tested with no
+// box test at all. A hit found that way (the primitive test rounds: it accepts rays that pass a little outside the primitive,
+// e.g. a ray that lies in the very plane of the box face it is tangent to) is the reference's hit. So the free walks probe such
+// a leaf: if a primitive there would be accepted, the ray goes to the reference's own walk, which decides.
+// The free walks' guarantees hold for rays that start within SceneDev::safe_r of safe_c (see build_nodes_ch: there the primitive
+// test's own rounding slack stays inside the boxes' margin). A ray from farther away -- a bounce off the ground sphere hundreds of
+// units out -- is traced by the reference's own walk.
+__device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float oy, float oz) {
+    if (WFPT_EXP_NO_TIE) return false;
+    const float fx = ox - sc.safe_c[0], fy = oy - sc.safe_c[1], fz = oz - sc.safe_c[2];
+    return (fx * fx + fy * fy) + fz * fz > sc.safe_r2;
+}
+
+template <int PRIM>
+__device__ __forceinline__ void probe_leaf(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float dx, float dy,
+                                           float dz, float a, float nearest, bool &risk) {
+    if (WFPT_EXP_NO_TIE) return;
+    float n2 = nearest;
+    uint32_t b2 = 0;
+    for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
+    if (n2 < nearest) risk = true;
 }
 
 template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH, bool EXACT>
@@ -491,9 +540,12 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf (ex:86-103); the root's own box is never tested (ex:84)
-            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest, risk))
+            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest, risk)) {
                 for (uint32_t i = 0; i < tr.prim_count; ++i)
                     hit_prim<PRIM, true>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best, &risk);
+            } else { // the reference does not test these primitives here -- but see probe_leaf
+                probe_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, dx, dy, dz, a, nearest, risk);
+            }
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
@@ -509,20 +561,41 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
 // enclosing the true box: struct Node4). The box test is the reference's arithmetic (hit_bvh_node: (b - o) * inv) on
 // boxes that are never smaller than the reference's, so every primitive the reference would test is still tested. Children are visited nearest first; the others go on a per-lane stack (LDS
 // column, spilling to global memory past kStack4Lds entries).
+// Entry k of a lane's stack: in LDS (s_stack[k * kExtendThreads + thread]) for k < kStack4Lds, beyond that in the global spill area
+// (spill[(k - kStack4Lds) * stride + block * kExtendThreads + thread]; at most a few percent of the pushes). The two bases and
+// the stride are uniform and the index is 32-bit, so neither access needs a per-lane 64-bit pointer -- a version that kept
+// "this lane's column" as pointers had them spilled to scratch and re-loaded at every pop -- and the LDS and the global access
+// stay two instructions of their own address space (a select between the two pointers would make every access a flat one).
+// (the lane index is re-derived with two v_mbcnt at every use -- as volatile asm, or the compiler hoists it out of the loop and,
+// short of registers, parks it in scratch: a scratch re-load in front of every pop)
+__device__ __forceinline__ uint32_t lane_id_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 struct Stack4 {
-    uint32_t *lds;    // this lane's LDS column: entry k at lds[k * kExtendThreads]
-    uint32_t *spill;  // the spill area (uniform): entry k (>= kStack4Lds) of global thread `col` at spill[(k - kStack4Lds) * stride + col]
+    uint32_t *lds;    // s_stack (uniform)
+    uint32_t *spill;  // the spill area (uniform)
     uint32_t stride;  // (uniform)
-    uint32_t col;     // this thread's column in the spill area
+    uint32_t wave0;   // first thread of this wave within the workgroup (uniform)
     uint32_t sp = 0;
     __device__ __forceinline__ void push(uint32_t w) {
-        if (sp < kStack4Lds) lds[sp * kExtendThreads] = w;
-        else spill[static_cast<size_t>(sp - kStack4Lds) * stride + col] = w;
+        if (sp < kStack4Lds) {
+            ((WFPT_AS_LDS uint32_t *)lds)[sp * kExtendThreads + wave0 + lane_id_now()] = w;
+        } else {
+            ((WFPT_AS_GLOBAL uint32_t *)spill)[(sp - kStack4Lds) * stride + blockIdx.x * kExtendThreads + wave0 + lane_id_now()] = w;
+        }
         sp += 1;
     }
     __device__ __forceinline__ uint32_t pop() {
         sp -= 1;
-        return sp < kStack4Lds ? lds[sp * kExtendThreads] : spill[static_cast<size_t>(sp - kStack4Lds) * stride + col];
+        uint32_t w;
+        if (sp < kStack4Lds) {
+            w = ((const WFPT_AS_LDS uint32_t *)lds)[sp * kExtendThreads + wave0 + lane_id_now()];
+        } else {
+            w = ((const WFPT_AS_GLOBAL uint32_t *)spill)[(sp - kStack4Lds) * stride + blockIdx.x * kExtendThreads + wave0 + lane_id_now()];
+        }
+        return w;
     }
 };
 
@@ -584,10 +657,10 @@ __device__ __forceinline__ Visit4 visit4_at(const float4 *nodes4, const float4 *
     float4 a, b, c, d;
     if (cur < tile_n) {
         const float4 *nd = tile + 4u * cur;
-        a = nd[0]; b = nd[1]; c = nd[2]; d = nd[3];
+        a = load4_lds(nd); b = load4_lds(nd + 1); c = load4_lds(nd + 2); d = load4_lds(nd + 3);
     } else {
         const float4 *nd = nodes4 + 4u * static_cast<size_t>(cur);
-        a = nd[0]; b = nd[1]; c = nd[2]; d = nd[3];
+        a = load4_global(nd); b = load4_global(nd + 1); c = load4_global(nd + 2); d = load4_global(nd + 3);
     }
     return visit4(a, b, c, d, r, nearest);
 }
@@ -624,9 +697,12 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
             // the quantised boxes above are LARGER than the caller's: the leaf's own box decides, with the reference's arithmetic
             // (see trace_ray_conservative), whether its primitives are tested
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest, risk))
+            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest, risk)) {
                 for (uint32_t i = 0; i < count; ++i)
                     hit_prim<PRIM, true>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best, &risk);
+            } else {
+                probe_leaf<PRIM>(prim_geom, first, count, ox, oy, oz, dx, dy, dz, a, nearest, risk);
+            }
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
     }
@@ -718,18 +794,17 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
                 hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
                                                                 prim);
             else if (LDS_SCENE) {
-                bool risk = false;
-                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
-                if (risk) // a near-tie: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                bool risk = far_origin(a.scene, ox, oy, oz);
+                if (!risk) hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
+                if (risk) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
                     hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(g_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
-                st.lds = s_stack + threadIdx.x;
+                st.lds = s_stack;
                 st.stride = a.scene.spill_stride;
-                st.spill = a.scene.stack_spill;
-                st.col = blockIdx.x * kExtendThreads + threadIdx.x;
-                bool risk = false;
-                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
+                st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+                bool risk = far_origin(a.scene, ox, oy, oz);
+                if (!risk) hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
                 if (risk)
                     hit = trace_ray<Trail, PRIM, uint32_t, 0, true>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, nullptr, ox, oy, oz, dx, dy, dz,
                                                                      a.scene.n_nodes, t, prim);
@@ -1337,18 +1412,17 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             if (LDS_SCENE && EXACT)
                 hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             else if (LDS_SCENE) {
-                bool risk = false;
-                hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
-                if (risk) // a near-tie: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                bool risk = far_origin(a.scene, ox, oy, oz);
+                if (!risk) hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
+                if (risk) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
                     hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(g_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
-                st.lds = L.stack + threadIdx.x;
+                st.lds = L.stack;
                 st.stride = a.scene.spill_stride;
-                st.spill = a.scene.stack_spill;
-                st.col = blockIdx.x * kExtendThreads + threadIdx.x;
-                bool risk = false;
-                hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
+                st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+                bool risk = far_origin(a.scene, ox, oy, oz);
+                if (!risk) hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
                 if (risk)
                     hit = trace_ray<Trail, PRIM, uint32_t, 0, true>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, nullptr, ox, oy, oz, dx, dy, dz,
                                                                      a.scene.n_nodes, t, prim);
@@ -1434,10 +1508,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     const wfpt_frame_buffer fb0 = a.ctl->frame;
     const uint32_t lane = lane_id();
     Stack4 st;
-    st.lds = s_stack + threadIdx.x;
+    st.lds = s_stack;
     st.stride = a.scene.spill_stride;
-    st.spill = a.scene.stack_spill;
-    st.col = blockIdx.x * kExtendThreads + threadIdx.x;
+    st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     const float4 *nodes4 = a.scene.nodes4;
 
     // per-lane ray and traversal state
@@ -1493,7 +1566,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                     r4 = make_ray4(ox, oy, oz, dx, dy, dz);
                     nearest = 1e30f; best = 0xffffffffu; cur = 0; st.sp = 0; budget = a.scene.n_nodes;
                     alive = true;
-                    risk = false;
+                    risk = far_origin(a.scene, ox, oy, oz); // (such a ray still runs the four-wide walk; the re-trace at its end decides)
                 }
             }
         }
@@ -1531,9 +1604,12 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
                 const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
                 const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
-                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, ix, iy, iz, nearest, risk)) // see trace_ray4
+                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, ix, iy, iz, nearest, risk)) { // see trace_ray4
                     for (uint32_t i = 0; i < count; ++i)
                         hit_prim<PRIM, true>(a.scene.prim_geom, first + i, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best, &risk);
+                } else {
+                    probe_leaf<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, risk);
+                }
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
