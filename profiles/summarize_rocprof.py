@@ -13,8 +13,8 @@ Writes
 
 HBM bytes: FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
 (MI355X_MICROARCH.md "HBM"); other widths are uncalibrated, so the read side is calibrated on `accumulate_kernel`, whose
-byte count is known exactly (it reads (samples + 1) x 12 B/pixel with 16 B per lane); both raw and corrected figures are
-reported. WRITE_SIZE is exact for 16-byte-per-lane stores.
+byte count is known exactly (it reads samples x 16 B/pixel of throughput images plus 12 B/pixel of `accumulated`, 16 B per
+lane); both raw and corrected figures are reported. WRITE_SIZE is exact for 16-byte-per-lane stores.
 """
 import collections
 import csv
@@ -67,11 +67,12 @@ def main():
     summary = {"kernel": dom, "bench_command": "python3 bench.py " + " ".join(sys.argv[7:]) if len(sys.argv) > 7 else None}
     steps = line["steps"]
     batches = line["config"]["samples_in_flight"]
+    summary["samples_in_flight"] = batches[0] if len(batches) == 1 else batches
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
         fetch_kib, write_kib = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
         cal = None
         if "FETCH_SIZE" in acc and len(batches) == 1:
-            true_read = (batches[0] + 1) * 12.0 * n_pixels  # every accumulate launch of this command carries the same batch
+            true_read = (batches[0] * 16.0 + 12.0) * n_pixels  # every accumulate launch of this command carries the same batch
             cal = true_read / (acc["FETCH_SIZE"]["mean"] * 1024.0)
         hbm = ((cal or 1.0) * fetch_kib + write_kib) * 1024.0
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
@@ -86,8 +87,8 @@ def main():
             "hbm_bytes_per_algorithmic_byte": hbm / alg,
             "note": f"means over every launch of the dominant kernel in `bench.py --steps {steps} --warmup {line['warmup']}` "
                     f"({batches} samples in flight); FETCH_SIZE x calibration (gfx950 reports half the bytes of wide reads; "
-                    "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE exact. bench.py scales "
-                    "hbm_bytes_per_algorithmic_byte by its own run's algorithmic bytes per launch."})
+                    "calibrated on accumulate, whose bytes are known exactly); WRITE_SIZE exact. bench.py quotes "
+                    "hbm_bytes_per_launch as roofline.traffic when its own run has the same samples in flight."})
     # average duration of the dominant kernel in the UNPROFILED-counter pass (rocprofv3 --kernel-trace --stats)
     avg_ns = None
     if stats:
@@ -104,13 +105,17 @@ def main():
                                 "valu_insts_per_launch": k["SQ_INSTS_VALU"]["mean"], "salu_insts_per_launch": k["SQ_INSTS_SALU"]["mean"],
                                 "lds_insts_per_launch": k["SQ_INSTS_LDS"]["mean"]}
         if avg_ns:
-            # What bounds the traversal is wave64 VALU ISSUE. tools/microbench_valu.hip (profiles/r02_microbench_valu.txt): a SIMD
-            # of this chip sustains one independent v_fma_f32 per 1.26 ns with 8 waves resident (3.0 cycles at the nominal
-            # 2.4 GHz: the clock drops under an all-VALU load), 1.38-1.46 ns for compare + select mixes.
+            # VALU issue. tools/microbench_valu.hip (profiles/r03_microbench_valu.txt), chip-wide wall-clock rates: a SIMD sustains
+            # ~0.95-1.0 wave64 instructions per ns of the FULL-RATE class (v_fma / v_mul / v_add / v_and: ~2.3 cycles each at the
+            # clock the load leaves) and ~0.58 per ns of the HALF-RATE class (v_min / v_max / v_min3 / v_max3 / v_cndmask / v_cmp /
+            # v_lshl_add / v_cvt_f32_ubyte: ~4.1 cycles), 0.30 per ns of v_rcp / v_sqrt. The traversal's inner visit is about half
+            # and half (profiles/r03_isa_inner_visit.txt), ~2.9 cycles per instruction: its issue ceiling is ~0.80 per ns per SIMD.
             rate = k["SQ_INSTS_VALU"]["mean"] / 1024.0 / avg_ns  # wave instructions per ns per SIMD
             summary["secondary"]["valu_issue_per_ns_per_simd"] = round(rate, 4)
-            summary["secondary"]["valu_issue_ceiling_per_ns_per_simd"] = 0.792
-            summary["secondary"]["valu_issue_frac"] = round(rate / 0.792, 4)
+            summary["secondary"]["valu_issue_ceiling_per_ns_per_simd"] = {"full_rate_ops": 0.95, "half_rate_ops": 0.58, "inner_visit_mix": 0.80}
+            summary["secondary"]["valu_issue_frac_of_visit_mix_ceiling"] = round(rate / 0.80, 4)
+            if "GRBM_GUI_ACTIVE" in k:
+                summary["secondary"]["shader_clock_ghz"] = round(k["GRBM_GUI_ACTIVE"]["mean"] / 8.0 / avg_ns, 3)
         if "SQ_WAIT_ANY" in k and "SQ_WAVE_CYCLES" in k:
             summary["secondary"]["wait_any_frac"] = round(k["SQ_WAIT_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)
             summary["secondary"]["wait_inst_any_frac"] = round(k["SQ_WAIT_INST_ANY"]["mean"] / k["SQ_WAVE_CYCLES"]["mean"], 4)

@@ -305,10 +305,18 @@ struct Traversal {
 // rounding error beyond a hit inside it is skipped or not depending on what was found before). The walks that are free in
 // their visit order (trace_ray_conservative, trace_ray4) watch for this and hand such a ray to the reference's own walk.
 __device__ __forceinline__ bool near_tie(float t, float nearest) { return !WFPT_EXP_NO_TIE && __builtin_fabsf(t - nearest) <= nearest * 3.8146973e-6f; }
+// How a free walk marks "hand this ray over": no flag of its own (a lane mask kept alive across the whole loop nest cost the
+// kernel ~40 scalar registers' worth of spills) but a poisoned result: nearest = -1 makes every later box and primitive test
+// fail, so the walk runs out by itself, and best = kHandOver tells the caller why.
+constexpr uint32_t kHandOver = 0xfffffffeu;
+__device__ __forceinline__ void hand_over(float &nearest, uint32_t &best) {
+    nearest = -1.0f;
+    best = kHandOver;
+}
 
 template <int PRIM, bool TRACK = false>
 __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float ox, float oy, float oz, float dx, float dy,
-                                         float dz, float a, float &nearest, uint32_t &best, bool *risk = nullptr) {
+                                         float dz, float a, float &nearest, uint32_t &best) {
     if (PRIM == 0) {
         const float4 s = geom[idx];
         const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
@@ -318,14 +326,16 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
         if (discrim >= 0.0f) {
             const float sq = sqrt_(discrim);
             float t = (-b - sq) / a;
-            if (TRACK && t > 0.001f && near_tie(t, nearest)) *risk = true;
-            if (t > 0.001f && t < nearest) {
+            if (TRACK && t > 0.001f && near_tie(t, nearest)) {
+                hand_over(nearest, best);
+            } else if (t > 0.001f && t < nearest) {
                 nearest = t;
                 best = idx;
             } else {
                 t = (-b + sq) / a;
-                if (TRACK && t > 0.001f && near_tie(t, nearest)) *risk = true;
-                if (t > 0.001f && t < nearest) {
+                if (TRACK && t > 0.001f && near_tie(t, nearest)) {
+                    hand_over(nearest, best);
+                } else if (t > 0.001f && t < nearest) {
                     nearest = t;
                     best = idx;
                 }
@@ -343,8 +353,9 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
             const float v = ((dx * qx + dy * qy) + dz * qz) * inv_det;
             if (v >= 0.0f && u + v <= 1.0f) {
                 const float t = ((e2.x * qx + e2.y * qy) + e2.z * qz) * inv_det;
-                if (TRACK && t > 0.001f && near_tie(t, nearest)) *risk = true;
-                if (t > 0.001f && t < nearest) {
+                if (TRACK && t > 0.001f && near_tie(t, nearest)) {
+                    hand_over(nearest, best);
+                } else if (t > 0.001f && t < nearest) {
                     nearest = t;
                     best = idx;
                 }
@@ -374,13 +385,16 @@ __device__ __forceinline__ void grow_prim_box(const float4 *geom, uint32_t idx, 
 // trace_ray_conservative for why that makes the set of tested primitives exactly the reference's.
 template <int PRIM>
 __device__ __forceinline__ bool leaf_box_passes(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float ix,
-                                                float iy, float iz, float nearest, bool &risk) {
+                                                float iy, float iz, float &nearest, uint32_t &best) {
     if (WFPT_EXP_NO_LEAFBOX) return true;
     float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
     float tmin, tmax;
     slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
-    if (near_tie(tmin, nearest)) risk = true; // `tmin > nearest` decided by a rounding error: see near_tie
+    if (near_tie(tmin, nearest)) { // `tmin > nearest` decided by a rounding error: see near_tie
+        hand_over(nearest, best);
+        return true; // (nothing passes the poisoned window any more)
+    }
     return !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
 }
 
@@ -401,12 +415,12 @@ __device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float o
 
 template <int PRIM>
 __device__ __forceinline__ void probe_leaf(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float dx, float dy,
-                                           float dz, float a, float nearest, bool &risk) {
+                                           float dz, float a, float &nearest, uint32_t &best) {
     if (WFPT_EXP_NO_TIE) return;
     float n2 = nearest;
     uint32_t b2 = 0;
     for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
-    if (n2 < nearest) risk = true;
+    if (n2 < nearest) hand_over(nearest, best);
 }
 
 template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH, bool EXACT>
@@ -465,6 +479,70 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
     return nearest < 1e30f; // ex:157
 }
 
+// The reference's walk once more, for the hand-over of the free walks: same visits, same arithmetic and same results as
+// trace_ray<..., EXACT = true>, written as ONE flat loop (a step is an inner visit, a leaf, or one level of the climb to the
+// pending sibling). It runs for a handful of rays per million, so its speed is irrelevant; what matters is that it asks little
+// of the register allocator: the nested loops of trace_ray inlined beside the fast walk cost the fast walk scalar registers
+// (every saved exec mask of a loop nest is a pair), which came back as spill traffic around every work item.
+template <typename Trail, int PRIM, typename ParentT>
+__device__ __forceinline__ bool retrace_reference(const float4 *nodes, const float4 *prim_geom, const ParentT *pair_parent, float ox, float oy,
+                                                  float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out, uint32_t &prim_out) {
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float a = (dx * dx + dy * dy) + dz * dz;
+    float nearest = 1e30f;
+    uint32_t best = 0xffffffffu, node = 0, left_first = __float_as_uint(nodes[0].w), prim_count = __float_as_uint(nodes[1].w), climb = 0;
+    Trail trail = 0;
+    uint32_t budget = 4u * max_steps + 64u; // every node is visited once and climbed through at most once per pop
+    bool alive = true, popping = false;
+    while (alive && budget-- != 0u) {
+        if (popping) { // one step of Traversal::pop
+            if (climb != 0u) {
+                node = pair_parent[node >> 1];
+                climb -= 1u;
+            } else {
+                node ^= 1u;
+                left_first = __float_as_uint(nodes[2u * node].w);
+                prim_count = __float_as_uint(nodes[2u * node + 1u].w);
+                popping = false;
+            }
+            continue;
+        }
+        bool pop = false;
+        if (prim_count == 0u) { // ex:105-138
+            const float4 *pair = nodes + 2u * left_first;
+            const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
+            const float t_left = hit_bvh_node<true>(lmin, lmax, ox, oy, oz, ix, iy, iz, nearest);
+            const float t_right = hit_bvh_node<true>(rmin, rmax, ox, oy, oz, ix, iy, iz, nearest);
+            const bool swap = t_left > t_right;
+            const float t_near = swap ? t_right : t_left, t_far = swap ? t_left : t_right;
+            if (t_near > nearest) {
+                pop = true;
+            } else {
+                node = left_first + (swap ? 1u : 0u);
+                trail = (trail << 1) | static_cast<Trail>(t_far < nearest ? 1u : 0u);
+                left_first = __float_as_uint(swap ? rmin.w : lmin.w);
+                prim_count = __float_as_uint(swap ? rmax.w : lmax.w);
+            }
+        } else { // ex:86-103
+            for (uint32_t i = 0; i < prim_count; ++i) hit_prim<PRIM>(prim_geom, left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+            pop = true;
+        }
+        if (pop) {
+            if (trail == 0) {
+                alive = false;
+            } else {
+                climb = (sizeof(Trail) == 8) ? static_cast<uint32_t>(__ffsll(static_cast<long long>(trail)) - 1)
+                                             : static_cast<uint32_t>(__ffs(static_cast<int>(trail)) - 1);
+                trail = (trail >> climb) & ~static_cast<Trail>(1);
+                popping = true;
+            }
+        }
+    }
+    t_out = nearest;
+    prim_out = best;
+    return nearest < 1e30f;
+}
+
 // ---- the LDS-resident traversal as it runs by default: same walk, CONSERVATIVE test of inner boxes, EXACT test of leaf boxes
 // What must not change is the set of primitives whose exact test (hit_prim, ex:185-210) runs: that test rounds too (its
 // discriminant cancels ~1e-7 of b^2), so a sphere "hit" can be reported for a ray that passes ~1e-4 outside the sphere -- and
@@ -497,7 +575,7 @@ __device__ __forceinline__ bool trace_ray(const float4 *nodes, const float4 *pri
 template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
                                                        float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
-                                                       uint32_t &prim_out, bool &risk) {
+                                                       uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz; // dot(direction, direction), ex:190
     const float bx = min_(max_(ix, -1e30f), 1e30f), by = min_(max_(iy, -1e30f), 1e30f), bz = min_(max_(iz, -1e30f), 1e30f);
@@ -540,17 +618,17 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf (ex:86-103); the root's own box is never tested (ex:84)
-            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest, risk)) {
+            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest, best)) {
                 for (uint32_t i = 0; i < tr.prim_count; ++i)
-                    hit_prim<PRIM, true>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best, &risk);
+                    hit_prim<PRIM, true>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             } else { // the reference does not test these primitives here -- but see probe_leaf
-                probe_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, dx, dy, dz, a, nearest, risk);
+                probe_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, dx, dy, dz, a, nearest, best);
             }
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
     t_out = nearest;
-    prim_out = best;
+    prim_out = best; // kHandOver: the caller re-traces with the reference's walk
     return nearest < 1e30f; // ex:157
 }
 
@@ -667,7 +745,7 @@ __device__ __forceinline__ Visit4 visit4_at(const float4 *nodes4, const float4 *
 
 template <int PRIM>
 __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *prim_geom, Stack4 st, float ox, float oy, float oz, float dx,
-                                           float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out, bool &risk) {
+                                           float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz;
     const Ray4 r4 = make_ray4(ox, oy, oz, dx, dy, dz);
@@ -697,11 +775,11 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
             // the quantised boxes above are LARGER than the caller's: the leaf's own box decides, with the reference's arithmetic
             // (see trace_ray_conservative), whether its primitives are tested
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest, risk)) {
+            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest, best)) {
                 for (uint32_t i = 0; i < count; ++i)
-                    hit_prim<PRIM, true>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best, &risk);
+                    hit_prim<PRIM, true>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
             } else {
-                probe_leaf<PRIM>(prim_geom, first, count, ox, oy, oz, dx, dy, dz, a, nearest, risk);
+                probe_leaf<PRIM>(prim_geom, first, count, ox, oy, oz, dx, dy, dz, a, nearest, best);
             }
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
@@ -794,20 +872,22 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
                 hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t,
                                                                 prim);
             else if (LDS_SCENE) {
-                bool risk = far_origin(a.scene, ox, oy, oz);
-                if (!risk) hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
-                if (risk) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
-                    hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(g_nodes, s_sphere, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                prim = kHandOver;
+                if (!far_origin(a.scene, ox, oy, oz))
+                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                if (prim == kHandOver) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                    hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
                 st.lds = s_stack;
                 st.stride = a.scene.spill_stride;
                 st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
-                bool risk = far_origin(a.scene, ox, oy, oz);
-                if (!risk) hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
-                if (risk)
-                    hit = trace_ray<Trail, PRIM, uint32_t, 0, true>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, nullptr, ox, oy, oz, dx, dy, dz,
-                                                                     a.scene.n_nodes, t, prim);
+                prim = kHandOver;
+                if (!far_origin(a.scene, ox, oy, oz))
+                    hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
+                if (prim == kHandOver)
+                    hit = retrace_reference<Trail, PRIM, uint32_t>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, ox, oy, oz, dx, dy, dz,
+                                                                    a.scene.n_nodes, t, prim);
             } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32,
                                                                             s_stack + threadIdx.x, ox, oy, oz, dx, dy, dz,
@@ -1412,20 +1492,22 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             if (LDS_SCENE && EXACT)
                 hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             else if (LDS_SCENE) {
-                bool risk = far_origin(a.scene, ox, oy, oz);
-                if (!risk) hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim, risk);
-                if (risk) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
-                    hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(g_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                prim = kHandOver;
+                if (!far_origin(a.scene, ox, oy, oz))
+                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                if (prim == kHandOver) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                    hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
                 st.lds = L.stack;
                 st.stride = a.scene.spill_stride;
                 st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
-                bool risk = far_origin(a.scene, ox, oy, oz);
-                if (!risk) hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim, risk);
-                if (risk)
-                    hit = trace_ray<Trail, PRIM, uint32_t, 0, true>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, nullptr, ox, oy, oz, dx, dy, dz,
-                                                                     a.scene.n_nodes, t, prim);
+                prim = kHandOver;
+                if (!far_origin(a.scene, ox, oy, oz))
+                    hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
+                if (prim == kHandOver)
+                    hit = retrace_reference<Trail, PRIM, uint32_t>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, ox, oy, oz, dx, dy, dz,
+                                                                    a.scene.n_nodes, t, prim);
             } else
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
                                                                             ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
@@ -1520,7 +1602,6 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     // keeps the hot loop's registers free of them; more state here meant scratch spills inside the loop)
     float dx = 0, dy = 0, dz = 0, nearest = 1e30f;
     Ray4 r4 = {0, 0, 0, 0, 0, 0};
-    bool risk = false; // this lane's ray met a near-tie (near_tie): the reference's own walk re-traces it when it ends
     bool more = true; // rays left at the cursor (wave-uniform)
     for (;;) {
         // ---------------- refill: idle lanes take the next rays (one atomic per group)
@@ -1566,7 +1647,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                     r4 = make_ray4(ox, oy, oz, dx, dy, dz);
                     nearest = 1e30f; best = 0xffffffffu; cur = 0; st.sp = 0; budget = a.scene.n_nodes;
                     alive = true;
-                    risk = far_origin(a.scene, ox, oy, oz); // (such a ray still runs the four-wide walk; the re-trace at its end decides)
+                    if (far_origin(a.scene, ox, oy, oz)) hand_over(nearest, best); // (the walk then runs out at once; the re-trace at its end decides)
                 }
             }
         }
@@ -1604,20 +1685,20 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
                 const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
                 const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
-                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, ix, iy, iz, nearest, risk)) { // see trace_ray4
+                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, ix, iy, iz, nearest, best)) { // see trace_ray4
                     for (uint32_t i = 0; i < count; ++i)
-                        hit_prim<PRIM, true>(a.scene.prim_geom, first + i, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best, &risk);
+                        hit_prim<PRIM, true>(a.scene.prim_geom, first + i, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best);
                 } else {
-                    probe_leaf<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, risk);
+                    probe_leaf<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best);
                 }
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
         if (alive && fin) { // the ray is done: dense record in ray order (p = o + t d as shade reads it, sh:91)
-            if (risk) // rare: the reference's own walk over the caller's binary tree decides
-                (void)trace_ray<unsigned long long, PRIM, uint32_t, 0, true>(reinterpret_cast<const float4 *>(a.scene.nodes), a.scene.prim_geom,
-                                                                              a.scene.pair_parent32, nullptr, r4.ox, r4.oy, r4.oz, dx, dy, dz,
-                                                                              a.scene.n_nodes, nearest, best);
+            if (best == kHandOver) // rare: the reference's own walk over the caller's binary tree decides
+                (void)retrace_reference<unsigned long long, PRIM, uint32_t>(reinterpret_cast<const float4 *>(a.scene.nodes), a.scene.prim_geom,
+                                                                             a.scene.pair_parent32, r4.ox, r4.oy, r4.oz, dx, dy, dz, a.scene.n_nodes,
+                                                                             nearest, best);
             const size_t slot = smp * a.batch.queue_stride + ray;
             const bool hit = nearest < 1e30f; // ex:157
             a.dense_out[2u * slot] = make_float4(r4.ox + nearest * dx, r4.oy + nearest * dy, r4.oz + nearest * dz, __uint_as_float(pixel_idx));
