@@ -1147,15 +1147,6 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
     for (;;) {
         const orc_bvh_node *nd = &c->nodes[node];
         if (nd->prim_count > 0) {
-            if (leaf_exact == 2 && node != 0) {
-                float tmin = -INFINITY;
-                for (int ax = 0; ax < 3; ax++) {
-                    float t1 = (nd->aabb_min[ax] - ray->origin[ax]) * ray->inv_direction[ax];
-                    float t2 = (nd->aabb_max[ax] - ray->origin[ax]) * ray->inv_direction[ax];
-                    tmin = ax == 0 ? orc_min(t1, t2) : orc_max(orc_min(t1, t2), tmin);
-                }
-                if (model_near_tie(tmin, nearest)) risk = 1;
-            }
             /* the leaf's own box with the reference's arithmetic (the device recomputes it from the primitives; wfpt_create
              * checks that this equals the node's box); the root's box is never tested (ex:84) */
             if (node == 0 || !leaf_exact || !orc_leaf_rejected(nd, ray, nearest)) {

@@ -326,16 +326,22 @@ __device__ __forceinline__ void hit_prim(const float4 *geom, uint32_t idx, float
         if (discrim >= 0.0f) {
             const float sq = sqrt_(discrim);
             float t = (-b - sq) / a;
-            if (TRACK && t > 0.001f && near_tie(t, nearest)) {
-                hand_over(nearest, best);
-            } else if (t > 0.001f && t < nearest) {
+            if (TRACK) { // as selects, not branches: a poisoned window (nearest = -1) accepts nothing below
+                const bool tie = t > 0.001f && near_tie(t, nearest);
+                nearest = tie ? -1.0f : nearest;
+                best = tie ? kHandOver : best;
+            }
+            if (t > 0.001f && t < nearest) {
                 nearest = t;
                 best = idx;
             } else {
                 t = (-b + sq) / a;
-                if (TRACK && t > 0.001f && near_tie(t, nearest)) {
-                    hand_over(nearest, best);
-                } else if (t > 0.001f && t < nearest) {
+                if (TRACK) {
+                    const bool tie = t > 0.001f && near_tie(t, nearest);
+                    nearest = tie ? -1.0f : nearest;
+                    best = tie ? kHandOver : best;
+                }
+                if (t > 0.001f && t < nearest) {
                     nearest = t;
                     best = idx;
                 }
@@ -391,10 +397,10 @@ __device__ __forceinline__ bool leaf_box_passes(const float4 *geom, uint32_t fir
     for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
     float tmin, tmax;
     slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
-    if (near_tie(tmin, nearest)) { // `tmin > nearest` decided by a rounding error: see near_tie
-        hand_over(nearest, best);
-        return true; // (nothing passes the poisoned window any more)
-    }
+    // (`tmin > nearest` decided by a rounding error needs no watch of its own: a primitive in here that could win then has its t
+    // within a rounding error of `nearest`, which the primitive tests' near_tie sees -- the leaf is only skipped when
+    // tmin > nearest, and then probe_leaf runs those tests)
+    (void)best;
     return !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
 }
 
