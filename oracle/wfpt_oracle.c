@@ -1148,17 +1148,25 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
         const orc_bvh_node *nd = &c->nodes[node];
         if (nd->prim_count > 0) {
             /* the leaf's own box with the reference's arithmetic (the device recomputes it from the primitives; wfpt_create
-             * checks that this equals the node's box); the root's box is never tested (ex:84) */
-            if (node == 0 || !leaf_exact || !orc_leaf_rejected(nd, ray, nearest)) {
+             * checks that this equals the node's box); the root's box is never tested (ex:84). Mode 2 = visit_leaf of the device:
+             * the primitive tests run into a tentative result whatever the box says (with the near-tie watch); the box then
+             * decides between keeping it and, if something changed, handing the ray over. */
+            int enter = node == 0 || !leaf_exact || !orc_leaf_rejected(nd, ray, nearest);
+            if (leaf_exact == 2) {
+                float n2 = nearest;
+                orc_hit_payload t2 = temp;
+                int tie = 0;
                 for (uint32_t i = 0; i < nd->prim_count; i++) {
                     orc_hit_payload nh;
-                    if (leaf_exact == 2 && !c->triangles && model_sphere_risk(c, ray, nd->left_first + i, nearest)) risk = 1;
-                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) { nearest = nh.t; temp = nh; }
+                    if (!c->triangles && model_sphere_risk(c, ray, nd->left_first + i, n2)) tie = 1;
+                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, n2, &nh)) { n2 = nh.t; t2 = nh; }
                 }
-            } else if (leaf_exact == 2) { /* probe_leaf: a primitive of a leaf whose box fails would be accepted */
+                if (tie || (!enter && n2 < nearest)) risk = 1;
+                if (enter) { nearest = n2; temp = t2; }
+            } else if (enter) {
                 for (uint32_t i = 0; i < nd->prim_count; i++) {
                     orc_hit_payload nh;
-                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) risk = 1;
+                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) { nearest = nh.t; temp = nh; }
                 }
             }
             if (sp == 0) break;

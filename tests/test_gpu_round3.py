@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 from conftest import assert_bit_equal
-from helpers import inputs_for, make_mesh_oracle, make_mesh_tracer, make_oracle, make_tracer, mesh_inputs
+from helpers import (adversarial_rays as _adversarial_rays, close_pairs_scene as _close_pairs_scene, inputs_for, make_mesh_oracle,
+                     make_mesh_tracer, make_oracle, make_tracer, mesh_inputs)
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -54,116 +55,7 @@ def test_exact_traversal_on_an_lds_resident_mesh(gpu, orc, exact):
     pt.close(); o.close()
 
 
-# ------------------------------------------------------------------ rays aimed at the edges of the argument
-def _next(x, k):
-    """x moved by k ulps (float32)."""
-    x = np.float32(x)
-    for _ in range(abs(k)):
-        x = np.nextafter(x, np.float32(np.inf if k > 0 else -np.inf), dtype=np.float32)
-    return x
-
-
-def _adversarial_rays(W, spheres, nodes, n_max):
-    """Rays the conservative-box argument has to survive: head-on at the face centres of leaf and inner
-    boxes (two direction components exactly zero: infinite inverses), origins exactly on the box planes at the tops / sides
-    of spheres travelling along the plane (grazing), rays passing the centre of a sphere at r (1 +- k ulp) (near-tangent,
-    where the exact test decides by the last bit), the same tilted by a few ulp, and rays towards pairs of spheres whose
-    hits differ by a few ulp."""
-    rays = []
-
-    def add(o, d):
-        rays.append((np.asarray(o, np.float32), np.asarray(d, np.float32)))
-
-    axes = np.eye(3, dtype=np.float32)
-    boxes = [(nd["aabb_min"], nd["aabb_max"]) for i, nd in enumerate(nodes) if i != 1]
-    rng = np.random.default_rng(3)
-    for lo, hi in boxes[: n_max // 40]:
-        c = (lo + hi) * np.float32(0.5)
-        for ax in range(3):
-            for sgn in (-1.0, 1.0):
-                o = c.copy()
-                o[ax] = (hi[ax] + np.float32(3.0)) if sgn < 0 else (lo[ax] - np.float32(3.0))
-                add(o, axes[ax] * np.float32(sgn))                       # head-on at the face centre, axis-parallel
-                d = axes[ax] * np.float32(sgn)
-                d[(ax + 1) % 3] = np.float32(1e-7)
-                add(o, d)                                                 # almost axis-parallel: huge inverse
-                e = c.copy()                                              # along an EDGE of the box, in the face plane
-                e[ax] = hi[ax] if sgn > 0 else lo[ax]
-                e[(ax + 1) % 3] = lo[(ax + 1) % 3] - np.float32(2.0)
-                add(e, axes[(ax + 1) % 3])
-    pick = rng.permutation(len(spheres))[: n_max // 60]
-    for i in pick:
-        c = spheres["center"][i][:3].astype(np.float32)
-        r = np.float32(spheres["radius"][i])
-        for ax in range(3):
-            t_ax = (ax + 1) % 3
-            for k in (-4, -2, -1, 0, 1, 2, 4):
-                # origin on (or k ulp off) the plane that touches the sphere at its extreme point on axis `ax`, travelling in the plane
-                o = c.copy()
-                o[ax] = _next(c[ax] + r, k)
-                o[t_ax] = c[t_ax] - np.float32(2.0) * r - np.float32(1.0)
-                add(o, axes[t_ax])
-                d = axes[t_ax].copy()
-                d[ax] = np.float32(k) * np.float32(1e-8)                  # tilted by next to nothing towards / away from the sphere
-                add(o, d)
-            # near-tangent in a random direction: pass the centre at distance r (1 + k 2^-23)
-            u = rng.normal(size=3).astype(np.float32)
-            u /= np.float32(np.linalg.norm(u))
-            v = np.cross(u, rng.normal(size=3)).astype(np.float32)
-            v /= np.float32(np.linalg.norm(v))
-            for k in (-3, -1, 0, 1, 3):
-                p = c + v * (r * (np.float32(1.0) + np.float32(k) * np.float32(2.0 ** -23)))
-                add(p - u * np.float32(5.0), u)
-    # neighbours: rays through the midpoints between close sphere pairs (two hits within a few ulp of each other are most
-    # likely where spheres nearly touch or overlap)
-    cs = spheres["center"][:, :3].astype(np.float64)
-    for i in pick[:40]:
-        dist = np.linalg.norm(cs - cs[i], axis=1)
-        dist[i] = np.inf
-        j = int(np.argmin(dist))
-        m = ((cs[i] + cs[j]) * 0.5).astype(np.float32)
-        for _ in range(4):
-            u = rng.normal(size=3).astype(np.float32)
-            u /= np.float32(np.linalg.norm(u))
-            add(m - u * np.float32(4.0), u)
-    rays = rays[:n_max]
-    out = np.zeros(len(rays), W.RAY)
-    for k, (o, d) in enumerate(rays):
-        out["origin"][k, :3] = o
-        out["origin"][k, 3] = 1.0
-        out["direction"][k, :3] = d
-    with np.errstate(all="ignore"):
-        out["inv_direction"] = (np.float32(1.0) / out["direction"][:, :3]).astype("<f4")
-    out["pixel_idx"] = np.arange(len(out), dtype="<u4") % 1024
-    return out
-
-
-def _close_pairs_scene(orc):
-    """A scene made for ties: pairs of spheres whose centres differ by 1-4 ulp (equal radii), nested and overlapping
-    spheres, plus a ground sphere; BVH built by the oracle's builder."""
-    rng = np.random.default_rng(11)
-    sp = np.zeros(81, orc.SPHERE)
-    mt = np.zeros(3, orc.MATERIAL)
-    mt["albedo"][:] = (0.7, 0.6, 0.5, 1.0)
-    mt["material_type"] = (0, 1, 2)
-    mt["refract_index"][2] = 1.5
-    sp["center"][0] = (0.0, -1000.0, 0.0, 1.0)
-    sp["radius"][0] = 1000.0
-    for k in range(40):
-        c = rng.uniform(-6, 6, 3).astype(np.float32)
-        c[1] = np.float32(abs(c[1]) * 0.3 + 0.5)
-        r = np.float32(rng.uniform(0.2, 0.6))
-        c2 = c.copy()
-        c2[k % 3] = _next(c2[k % 3], 1 + k % 4)
-        sp["center"][1 + 2 * k, :3], sp["center"][2 + 2 * k, :3] = c, c2
-        sp["radius"][1 + 2 * k] = r
-        sp["radius"][2 + 2 * k] = r if k % 2 == 0 else _next(r, 1)
-    sp["center"][:, 3] = 1.0
-    sp["material_idx"] = np.arange(len(sp)) % 3
-    sp["material_type"] = np.arange(len(sp)) % 3
-    return sp, mt
-
-
+# ------------------------------------------------------------------ rays aimed at the edges of the argument (builders: helpers.py)
 @pytest.mark.parametrize("scene", ["shirley", "pairs"])
 @pytest.mark.parametrize("exact", [False, True])
 def test_adversarial_rays_against_the_oracle(gpu, orc, scene, exact):

@@ -137,3 +137,31 @@ def test_counter_example_visit_order_decides_a_tie(orc):
     assert cnt >= 1 and 974707 in rows[:, 0]
     assert _mismatches(O, o, n, extent, 2)[0] == 0
     o.close()
+
+
+@pytest.mark.parametrize("scene", ["shirley", "pairs"])
+def test_adversarial_rays_model_equals_reference(orc, scene):
+    """The rays of tests/test_gpu_round3.py::test_adversarial_rays_against_the_oracle (head-on at box face centres, in face planes,
+    along box edges, grazing spheres at their extreme points, near-coincident sphere pairs) through the CPU model of the device's
+    walk: no difference from the reference's walk; without the hand-over (mode 1) there are dozens, all of the kinds
+    wfpt_kernels.hip names (blind descent into a box the ray misses; which of two near-equal hits is met first)."""
+    from helpers import adversarial_rays, close_pairs_scene, inputs_for, make_oracle
+    O = orc
+    import types
+    W = types.SimpleNamespace(RAY=O.RAY)
+    w, h = 128, 64
+    if scene == "shirley":
+        inputs = inputs_for(O, "shirley", w, h)
+    else:
+        sp, mt = close_pairs_scene(O)
+        sp_o, nodes = O.build_bvh(sp.copy())
+        cam, ip, vw = O.shirley_camera(w, h)
+        inputs = (sp_o, mt, nodes, cam, ip, vw)
+    o = make_oracle(O, inputs, w, h)
+    rays = adversarial_rays(W, inputs[0], inputs[2], w * h)
+    n = len(rays)
+    o.set_frame(1, 0); o.write_rays(rays.view(O.RAY)); o.set_counters([0, 0, n])
+    extent = _extent(O, inputs[2], inputs[3], inputs[0])
+    assert _mismatches(O, o, n, extent, 2)[0] == 0
+    assert _mismatches(O, o, n, extent, 1)[0] > 20
+    o.close()

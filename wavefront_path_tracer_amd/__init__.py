@@ -207,6 +207,7 @@ def lib():
         "wfpt_save_ppm": (i32, [vp, C.c_char_p]),
         "wfpt_save_pfm": (i32, [vp, C.c_char_p]),
         "wfpt_debug_extend_blocks_per_cu": (i32, [i32, u32]),
+        "wfpt_debug_read_stamps": (i32, [vp, vp, i32]),
         "wfpt_debug_bvh4": (i32, [vp, u32, vp]),
     }
     for name, (res, args) in sig.items():

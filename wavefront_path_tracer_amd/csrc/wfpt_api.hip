@@ -79,6 +79,7 @@ struct wfpt_ctx {
     int comm_rank = 0, comm_world = 1;
     float *gather_stage = nullptr; // root: [world - 1] slabs received from the peers
     float *gather_frame = nullptr; // root: assembled frame, whole bands (ceil(height / 8) * 8 rows)
+    unsigned long long *d_stamps = nullptr; // diagnostic builds: 16 counters (wfpt_debug_read_stamps)
     float4 *rec_dense = nullptr; // HBM-resident scenes: per-ray results of the refill traversal, [batch][capacity][2]
     uint32_t classic_batch = 1; // slices of the stage-by-stage queues: batch_max when the loop runs unfused, else 1 (stage API)
     uint32_t bounce_blocks_per_cu = 1;
@@ -320,6 +321,7 @@ AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping,
 BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb) {
     BounceArgs a{};
     a.batch = batch_of(c, nb);
+    a.stamps = c->d_stamps;
     a.rec_in = c->rec_mem[in_parity];
     a.rec_out = c->rec_mem[out_parity];
     a.in_hits = c->f_chunk_hits[in_parity];
@@ -562,7 +564,7 @@ int stage_end(wfpt_ctx *c, int stage) {
 //  (b) the rounding slack of the PRIMITIVE test: the reference's sphere test (ex:185-210) accepts a ray that passes up to
 //      about 6 * 2^-24 * D^2 / r outside a sphere of radius r whose centre is D away from the ray's origin (its discriminant
 //      b^2 - a c cancels ~12 * 2^-24 * a |o - c|^2). Such a "hit" is the reference's hit whenever the reference tests the
-//      primitive -- through a leaf box that passes, or blindly (probe_leaf) -- so the free walk must at least REACH every
+//      primitive -- through a leaf box that passes, or blindly (visit_leaf) -- so the free walk must at least REACH every
 //      leaf the ray passes that close to: margin >= slack, i.e. D <= sqrt(margin * r / (6 * 2^-24)). safe_region() turns this
 //      into one ball of origins per scene; rays from outside it are traced by the reference's own walk (far_origin).
 constexpr int kMarginLog2 = -17;
@@ -1016,6 +1018,8 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(dmalloc(&c->ctl, kMaxBatch));
     CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control) * kMaxBatch, c->stream));
     CREATE_HIP(dmalloc(&c->camera, 1));
+    CREATE_HIP(dmalloc(&c->d_stamps, 16));
+    CREATE_HIP(hipMemsetAsync(c->d_stamps, 0, sizeof(unsigned long long) * 16, c->stream));
 
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -1140,7 +1144,7 @@ void wfpt_destroy(wfpt_ctx *c) {
                     c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg,
                     c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
-                    c->camera};
+                    c->camera, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1769,6 +1773,19 @@ int wfpt_save_pfm(wfpt_ctx *c, const char *path) {
     for (uint32_t y = c->height; y-- > 0 && ok;) ok = std::fwrite(acc.data() + y * row, sizeof(float), row, f) == row;
     std::fclose(f);
     return ok ? WFPT_OK : fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_pfm: short write");
+}
+
+int wfpt_debug_read_stamps(wfpt_ctx *c, uint64_t out[16], int reset) {
+    // Diagnostic builds of the library (-DWFPT_STAMPS=1, tools/build_variant.sh) add up, over the waves of the middle bounce
+    // launches, the shader cycles per phase of a work item: [0] item start -> walk start (shade), [1] the walk, [2] waiting for the
+    // other waves at the barrier, [3] compaction + stores, [4] wave-items, [5] live rays; [8] wave-level inner visits, [9]
+    // wave-level leaf rounds, [10] lane-level inner visits. The shipped library leaves them zero.
+    if (!c || !out) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_debug_read_stamps: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, hipMemcpy(out, c->d_stamps, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost));
+    if (reset) WFPT_HIP(c, hipMemset(c->d_stamps, 0, sizeof(uint64_t) * 16));
+    return WFPT_OK;
 }
 
 int wfpt_debug_extend_blocks_per_cu(int device, uint32_t lds_bytes) {

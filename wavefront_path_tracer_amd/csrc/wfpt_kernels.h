@@ -210,6 +210,7 @@ constexpr int kMissSegsPerItem = WFPT_MISS_SEGS; // miss work item = this many i
 
 struct BounceArgs {
     Batch batch;
+    unsigned long long *stamps; // diagnostic builds (-DWFPT_STAMPS=1): per-phase wave-cycle sums, see wfpt_debug_read_stamps
     const float4 *rec_in;   // [batch][capacity][2]: (p.xyz | pixel), (d.xyz | prim) of the previous wavefront's hits
     float4 *rec_out;
     const uint32_t *in_hits, *in_hit_base, *in_miss; // per-segment counts / bases of the previous wavefront (scan's output)

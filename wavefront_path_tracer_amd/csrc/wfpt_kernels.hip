@@ -215,6 +215,20 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
 #ifndef WFPT_EXP_NO_LEAFBOX
 #define WFPT_EXP_NO_LEAFBOX 0 // 1: leaf boxes are not re-tested with the reference's arithmetic
 #endif
+#ifndef WFPT_STAMPS
+#define WFPT_STAMPS 0 // 1: diagnostic build; the middle bounce launches add up, per wave, the shader cycles (s_memtime) spent in each phase
+#endif
+#if WFPT_STAMPS
+#define WFPT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+// per-lane step counters of the free walk, in registers: [0] loop trips of the inner-visit loop as this WAVE ran them (a uniform
+// count carried through readfirstlane), [1] leaf rounds of the wave, [2] this lane's own inner visits
+#define WFPT_DBG_PARAM , uint32_t (&dbg)[3]
+#define WFPT_DBG_ARG , dbg
+#else
+#define WFPT_STAMP(var)
+#define WFPT_DBG_PARAM
+#define WFPT_DBG_ARG
+#endif
 #ifndef WFPT_BUDGET_INNER
 #define WFPT_BUDGET_INNER 0 // 1: count the step budget down on every inner visit as well (costs 3 instructions per visit)
 #endif
@@ -386,30 +400,6 @@ __device__ __forceinline__ void grow_prim_box(const float4 *geom, uint32_t idx, 
         hi = {max_(hi.x, max_(max_(v0.x, bx), cx)), max_(hi.y, max_(max_(v0.y, by), cy)), max_(hi.z, max_(max_(v0.z, bz), cz))};
     }
 }
-// The reference's own test (ex:164-183) of the box of a LEAF holding primitives [first, first + count).
-// Every traversal below that is free in how it prunes INNER boxes applies this before it tests a leaf's primitives: see
-// trace_ray_conservative for why that makes the set of tested primitives exactly the reference's.
-template <int PRIM>
-__device__ __forceinline__ bool leaf_box_passes(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float ix,
-                                                float iy, float iz, float &nearest, uint32_t &best) {
-    if (WFPT_EXP_NO_LEAFBOX) return true;
-    float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
-    float tmin, tmax;
-    slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
-    // (`tmin > nearest` decided by a rounding error needs no watch of its own: a primitive in here that could win then has its t
-    // within a rounding error of `nearest`, which the primitive tests' near_tie sees -- the leaf is only skipped when
-    // tmin > nearest, and then probe_leaf runs those tests)
-    (void)best;
-    return !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
-}
-
-// A leaf the free walk has reached but whose own box FAILS the reference's test. The reference does not test its primitives on
-// that account -- but it may test them all the same: while nothing is hit yet, a pair of boxes the ray misses both of is still
-// entered, left child first (ex:124, `1e30 > 1e30`), down to the leftmost leaf below, whose primitives are then tested with no
-// box test at all. A hit found that way (the primitive test rounds: it accepts rays that pass a little outside the primitive,
-// e.g. a ray that lies in the very plane of the box face it is tangent to) is the reference's hit. So the free walks probe such
-// a leaf: if a primitive there would be accepted, the ray goes to the reference's own walk, which decides.
 // The free walks' guarantees hold for rays that start within SceneDev::safe_r of safe_c (see build_nodes_ch: there the primitive
 // test's own rounding slack stays inside the boxes' margin). A ray from farther away -- a bounce off the ground sphere hundreds of
 // units out -- is traced by the reference's own walk.
@@ -419,14 +409,40 @@ __device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float o
     return (fx * fx + fy * fy) + fz * fz > sc.safe_r2;
 }
 
+// A leaf of a free walk. ONE pass over its primitives grows the leaf's own box exactly as the builder computes it (the reference's
+// test of that box, ex:164-183, is what decides whether these primitives are tested: see trace_ray_conservative) and runs the
+// primitive tests into a tentative result; then the box decides.
+//   * Box entered (or never tested: the root, ex:84): the tentative result stands.
+//   * Box failed: the reference does not test these primitives on that account -- but it may test them all the same. While
+//     nothing is hit yet, a pair of boxes the ray misses both of is still entered, left child first (ex:124, `1e30 > 1e30`),
+//     down to the leftmost leaf below, whose primitives are then tested with no box test at all; and a primitive test rounds,
+//     so it can accept a ray that passes a little outside the primitive (e.g. one that lies in the very plane of the box face
+//     it is tangent to). A hit found that way is the reference's hit. So if a primitive here WOULD have been accepted, the ray
+//     is handed to the reference's own walk, which decides; if none would, entering or not makes no difference.
+// Each primitive is fetched once (they come from global memory for scenes beyond LDS).
 template <int PRIM>
-__device__ __forceinline__ void probe_leaf(const float4 *geom, uint32_t first, uint32_t count, float ox, float oy, float oz, float dx, float dy,
-                                           float dz, float a, float &nearest, uint32_t &best) {
-    if (WFPT_EXP_NO_TIE) return;
+__device__ __forceinline__ void visit_leaf(const float4 *geom, uint32_t first, uint32_t count, bool box_untested, float ox, float oy, float oz,
+                                           float dx, float dy, float dz, float ix, float iy, float iz, float a, float &nearest, uint32_t &best) {
+    float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     float n2 = nearest;
-    uint32_t b2 = 0;
-    for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
-    if (n2 < nearest) hand_over(nearest, best);
+    uint32_t b2 = best;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (!WFPT_EXP_NO_LEAFBOX) grow_prim_box<PRIM>(geom, first + i, lo, hi);
+        hit_prim<PRIM, true>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
+    }
+    bool enter = box_untested || WFPT_EXP_NO_LEAFBOX;
+    if (!enter) {
+        float tmin, tmax;
+        slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
+        enter = !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
+    }
+    const bool changed = n2 < nearest; // a primitive was accepted (or a near-tie poisoned the window: n2 = -1)
+    if (enter) {
+        nearest = n2;
+        best = b2;
+    } else if (changed && !WFPT_EXP_NO_TIE) {
+        hand_over(nearest, best);
+    }
 }
 
 template <typename Trail, int PRIM, typename ParentT, uint32_t STACK_DEPTH, bool EXACT>
@@ -555,7 +571,7 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 // the reference never sees it, because the ray misses the sphere's BOX and the leaf is never entered. (Found by
 // tools/hunt_conservative.py: with every box grown, 2 rays in 1.6e8 reported such a hit; in the dispatch-keyed RNG mode one
 // changed hit re-keys the rest of the sample.) So boxes are filters the result depends on, and they are treated in two classes:
-//   * LEAF boxes are tested with the reference's own arithmetic (leaf_box_passes) when the walk arrives at the leaf;
+//   * LEAF boxes are tested with the reference's own arithmetic (visit_leaf) when the walk arrives at the leaf;
 //   * INNER boxes only have to say "maybe" whenever the reference's test would enter them.
 // That is enough, because the reference's test is MONOTONE in the box: IEEE subtraction and multiplication by a fixed inverse
 // are monotone, so for nested boxes L inside A (a BVH's boxes nest in float coordinates; checked at wfpt_create) every plane
@@ -569,7 +585,7 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 // MORE than this test's own rounding error can reach (build_nodes_ch, wfpt_api.hip): for every ray whose origin lies within
 // four scene extents of the origin, computed entry distance <= the exact box's and computed exit distance >= its exit
 // distance. (wfpt_create falls back to the exact test when a camera or an injected ray lies outside that range, when a box
-// is not finite, or when the caller's leaf boxes are not what leaf_box_passes recomputes.)
+// is not finite, or when the caller's leaf boxes are not what visit_leaf recomputes: tree_is_recomputable, wfpt_api.hip.)
 //   per axis: tc = c * inv - o * inv (one fma against the per-ray constant -(o * inv)),
 //             t_entry = tc - h * |inv|, t_exit = tc + h * |inv| (one fma each; the sign of inv needs no min / max),
 //   entered  <=> max(t_entry over axes, 0) <= min(t_exit over axes, nearest)
@@ -581,7 +597,7 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
                                                        float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
-                                                       uint32_t &prim_out) {
+                                                       uint32_t &prim_out WFPT_DBG_PARAM) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz; // dot(direction, direction), ex:190
     const float bx = min_(max_(ix, -1e30f), 1e30f), by = min_(max_(iy, -1e30f), 1e30f), bz = min_(max_(iz, -1e30f), 1e30f);
@@ -599,6 +615,10 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
     while (alive) {
         while (alive && tr.prim_count == 0) {
             if (WFPT_BUDGET_INNER && budget-- == 0) { alive = false; break; }
+#if WFPT_STAMPS
+            dbg[0] = __builtin_amdgcn_readfirstlane(dbg[0]) + 1u;
+            dbg[2] += 1u;
+#endif
             const float4 *pair = nodes_ch + 2u * tr.left_first;
             const float4 lc = pair[0], lh = pair[1], rc = pair[2], rh = pair[3];
             keep4(lc, lh, rc, rh);
@@ -624,12 +644,10 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf (ex:86-103); the root's own box is never tested (ex:84)
-            if (tr.node == 0u || leaf_box_passes<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, ix, iy, iz, nearest, best)) {
-                for (uint32_t i = 0; i < tr.prim_count; ++i)
-                    hit_prim<PRIM, true>(prim_geom, tr.left_first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
-            } else { // the reference does not test these primitives here -- but see probe_leaf
-                probe_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, ox, oy, oz, dx, dy, dz, a, nearest, best);
-            }
+#if WFPT_STAMPS
+            dbg[1] = __builtin_amdgcn_readfirstlane(dbg[1]) + 1u;
+#endif
+            visit_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, tr.node == 0u, ox, oy, oz, dx, dy, dz, ix, iy, iz, a, nearest, best);
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
@@ -781,12 +799,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
             // the quantised boxes above are LARGER than the caller's: the leaf's own box decides, with the reference's arithmetic
             // (see trace_ray_conservative), whether its primitives are tested
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            if (root_leaf || leaf_box_passes<PRIM>(prim_geom, first, count, ox, oy, oz, ix, iy, iz, nearest, best)) {
-                for (uint32_t i = 0; i < count; ++i)
-                    hit_prim<PRIM, true>(prim_geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
-            } else {
-                probe_leaf<PRIM>(prim_geom, first, count, ox, oy, oz, dx, dy, dz, a, nearest, best);
-            }
+            visit_leaf<PRIM>(prim_geom, first, count, root_leaf, ox, oy, oz, dx, dy, dz, ix, iy, iz, a, nearest, best);
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
     }
@@ -880,7 +893,12 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
             else if (LDS_SCENE) {
                 prim = kHandOver;
                 if (!far_origin(a.scene, ox, oy, oz))
-                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                {
+#if WFPT_STAMPS
+                    uint32_t dbg[3] = {0, 0, 0};
+#endif
+                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim WFPT_DBG_ARG);
+                }
                 if (prim == kHandOver) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
                     hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
@@ -1452,6 +1470,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             iter += 1;
             continue;
         }
+        WFPT_STAMP(t_item);
         while (item >= first_h + L.items_h[smp_h]) first_h += L.items_h[smp_h++]; // block-uniform
         const uint32_t smp = smp_h;
         const uint32_t seg_out = item - first_h;
@@ -1491,6 +1510,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             continue;
         }
         // ---------------- extend (ex:47-70) of the ray in registers
+        WFPT_STAMP(t_trace);
+#if WFPT_STAMPS
+        uint32_t dbg[3] = {0, 0, 0};
+#endif
         float t = 0.0f;
         uint32_t prim = 0;
         bool hit = false;
@@ -1500,7 +1523,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             else if (LDS_SCENE) {
                 prim = kHandOver;
                 if (!far_origin(a.scene, ox, oy, oz))
-                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim WFPT_DBG_ARG);
                 if (prim == kHandOver) // near-tie, probe or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
                     hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
@@ -1518,6 +1541,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 hit = trace_ray<Trail, PRIM, uint32_t, kStackDepth, EXACT>(g_nodes, a.scene.prim_geom, a.scene.pair_parent32, L.stack + threadIdx.x,
                                                                             ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
         }
+        WFPT_STAMP(t_traced);
         const bool miss = live && !hit;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
         if (lane == 0) {
@@ -1525,6 +1549,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             L.cnt[(buf * 2 + 1) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(miss_mask));
         }
         __syncthreads();
+        WFPT_STAMP(t_synced);
         uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kExtendWaves; ++w) {
@@ -1549,6 +1574,31 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             a.out_hits[co + seg_out] = hit_total;
             a.out_miss[co + seg_out] = miss_total;
         }
+#if WFPT_STAMPS
+        if (MODE == kBounceMiddle && a.stamps) { // per wave: cycles from item start to trace start (shade), in the walk, waiting at the barrier, writing
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WFPT_STAMP(t_done);
+            if (lane == 0) {
+                atomicAdd(&a.stamps[0], t_trace - t_item);
+                atomicAdd(&a.stamps[1], t_traced - t_trace);
+                atomicAdd(&a.stamps[2], t_synced - t_traced);
+                atomicAdd(&a.stamps[3], t_done - t_synced);
+                atomicAdd(&a.stamps[4], 1ull);
+                atomicAdd(&a.stamps[5], static_cast<unsigned long long>(__popcll(__ballot(live))));
+            }
+            uint32_t w_visits = dbg[0], w_leaves = dbg[1], l_visits = dbg[2];
+            for (int d = 1; d < 64; d <<= 1) { // the wave's trip counts = the maximum over its lanes; lane visits add up
+                w_visits = max(w_visits, static_cast<uint32_t>(__shfl_xor(w_visits, d, 64)));
+                w_leaves = max(w_leaves, static_cast<uint32_t>(__shfl_xor(w_leaves, d, 64)));
+                l_visits += static_cast<uint32_t>(__shfl_xor(l_visits, d, 64));
+            }
+            if (lane == 0) {
+                atomicAdd(&a.stamps[8], static_cast<unsigned long long>(w_visits));
+                atomicAdd(&a.stamps[9], static_cast<unsigned long long>(w_leaves));
+                atomicAdd(&a.stamps[10], static_cast<unsigned long long>(l_visits));
+            }
+        }
+#endif
         item = L.next[buf];
         iter += 1;
     }
@@ -1691,12 +1741,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
                 const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
                 const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
-                if (a.scene.root_leaf || leaf_box_passes<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, ix, iy, iz, nearest, best)) { // see trace_ray4
-                    for (uint32_t i = 0; i < count; ++i)
-                        hit_prim<PRIM, true>(a.scene.prim_geom, first + i, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best);
-                } else {
-                    probe_leaf<PRIM>(a.scene.prim_geom, first, count, r4.ox, r4.oy, r4.oz, dx, dy, dz, aa, nearest, best);
-                }
+                visit_leaf<PRIM>(a.scene.prim_geom, first, count, a.scene.root_leaf != 0, r4.ox, r4.oy, r4.oz, dx, dy, dz, ix, iy, iz, aa, nearest, best); // see trace_ray4
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
