@@ -219,7 +219,13 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
 #define WFPT_STAMPS 0 // 1: diagnostic build; the middle bounce launches add up, per wave, the shader cycles (s_memtime) spent in each phase
 #endif
 #if WFPT_STAMPS
-#define WFPT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+// (volatile asm with a memory clobber: the compiler may neither move nor merge these reads)
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#define WFPT_STAMP(var) const unsigned long long var = stamp_now()
 // per-lane step counters of the free walk, in registers: [0] loop trips of the inner-visit loop as this WAVE ran them (a uniform
 // count carried through readfirstlane), [1] leaf rounds of the wave, [2] this lane's own inner visits
 #define WFPT_DBG_PARAM , uint32_t (&dbg)[3]
@@ -409,9 +415,9 @@ __device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float o
     return (fx * fx + fy * fy) + fz * fz > sc.safe_r2;
 }
 
-// A leaf of a free walk. ONE pass over its primitives grows the leaf's own box exactly as the builder computes it (the reference's
-// test of that box, ex:164-183, is what decides whether these primitives are tested: see trace_ray_conservative) and runs the
-// primitive tests into a tentative result; then the box decides.
+// A leaf of a free walk. The primitive tests run into a TENTATIVE result; if that changed anything, the leaf's own box is grown
+// exactly as the builder computes it and the reference's test of that box (ex:164-183), which is what decides whether these
+// primitives are tested at all (see trace_ray_conservative), gives the verdict:
 //   * Box entered (or never tested: the root, ex:84): the tentative result stands.
 //   * Box failed: the reference does not test these primitives on that account -- but it may test them all the same. While
 //     nothing is hit yet, a pair of boxes the ray misses both of is still entered, left child first (ex:124, `1e30 > 1e30`),
@@ -419,29 +425,30 @@ __device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float o
 //     so it can accept a ray that passes a little outside the primitive (e.g. one that lies in the very plane of the box face
 //     it is tangent to). A hit found that way is the reference's hit. So if a primitive here WOULD have been accepted, the ray
 //     is handed to the reference's own walk, which decides; if none would, entering or not makes no difference.
-// Each primitive is fetched once (they come from global memory for scenes beyond LDS).
+// (If nothing changed, entering or not makes no difference either, and the box is never computed: the common case.)
 template <int PRIM>
 __device__ __forceinline__ void visit_leaf(const float4 *geom, uint32_t first, uint32_t count, bool box_untested, float ox, float oy, float oz,
                                            float dx, float dy, float dz, float ix, float iy, float iz, float a, float &nearest, uint32_t &best) {
-    float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     float n2 = nearest;
     uint32_t b2 = best;
-    for (uint32_t i = 0; i < count; ++i) {
-        if (!WFPT_EXP_NO_LEAFBOX) grow_prim_box<PRIM>(geom, first + i, lo, hi);
-        hit_prim<PRIM, true>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
-    }
-    bool enter = box_untested || WFPT_EXP_NO_LEAFBOX;
-    if (!enter) {
-        float tmin, tmax;
-        slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
-        enter = !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
-    }
-    const bool changed = n2 < nearest; // a primitive was accepted (or a near-tie poisoned the window: n2 = -1)
-    if (enter) {
-        nearest = n2;
-        best = b2;
-    } else if (changed && !WFPT_EXP_NO_TIE) {
-        hand_over(nearest, best);
+    for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM, true>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
+    // The box's verdict only matters if something changed (a primitive accepted, or a near-tie poisoned the window: n2 = -1):
+    // most leaf visits end here, without the box ever being computed.
+    if (n2 < nearest) {
+        bool enter = box_untested || WFPT_EXP_NO_LEAFBOX;
+        if (!enter) {
+            float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
+            float tmin, tmax;
+            slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
+            enter = !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
+        }
+        if (enter) {
+            nearest = n2;
+            best = b2;
+        } else if (!WFPT_EXP_NO_TIE) {
+            hand_over(nearest, best);
+        }
     }
 }
 
@@ -1435,6 +1442,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     const wfpt_frame_buffer fb0 = a.ctl->frame;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t iter = 0;
+#if WFPT_STAMPS
+    unsigned long long acc_cyc[4] = {0, 0, 0, 0};
+    uint32_t acc_cnt[5] = {0, 0, 0, 0, 0};
+#endif
     while (item < n_items) {
         const uint32_t buf = iter & 1u;
         if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
@@ -1575,33 +1586,37 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             a.out_miss[co + seg_out] = miss_total;
         }
 #if WFPT_STAMPS
-        if (MODE == kBounceMiddle && a.stamps) { // per wave: cycles from item start to trace start (shade), in the walk, waiting at the barrier, writing
+        if (MODE == kBounceMiddle) { // per wave, summed over its items in registers (flushed once, at the end of the kernel)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             WFPT_STAMP(t_done);
-            if (lane == 0) {
-                atomicAdd(&a.stamps[0], t_trace - t_item);
-                atomicAdd(&a.stamps[1], t_traced - t_trace);
-                atomicAdd(&a.stamps[2], t_synced - t_traced);
-                atomicAdd(&a.stamps[3], t_done - t_synced);
-                atomicAdd(&a.stamps[4], 1ull);
-                atomicAdd(&a.stamps[5], static_cast<unsigned long long>(__popcll(__ballot(live))));
-            }
+            acc_cyc[0] += t_trace - t_item;
+            acc_cyc[1] += t_traced - t_trace;
+            acc_cyc[2] += t_synced - t_traced;
+            acc_cyc[3] += t_done - t_synced;
+            acc_cnt[0] += 1u;
+            acc_cnt[1] += static_cast<uint32_t>(__popcll(__ballot(live)));
             uint32_t w_visits = dbg[0], w_leaves = dbg[1], l_visits = dbg[2];
             for (int d = 1; d < 64; d <<= 1) { // the wave's trip counts = the maximum over its lanes; lane visits add up
                 w_visits = max(w_visits, static_cast<uint32_t>(__shfl_xor(w_visits, d, 64)));
                 w_leaves = max(w_leaves, static_cast<uint32_t>(__shfl_xor(w_leaves, d, 64)));
                 l_visits += static_cast<uint32_t>(__shfl_xor(l_visits, d, 64));
             }
-            if (lane == 0) {
-                atomicAdd(&a.stamps[8], static_cast<unsigned long long>(w_visits));
-                atomicAdd(&a.stamps[9], static_cast<unsigned long long>(w_leaves));
-                atomicAdd(&a.stamps[10], static_cast<unsigned long long>(l_visits));
-            }
+            acc_cnt[2] += w_visits; acc_cnt[3] += w_leaves; acc_cnt[4] += l_visits;
         }
 #endif
         item = L.next[buf];
         iter += 1;
     }
+#if WFPT_STAMPS
+    if (MODE == kBounceMiddle && a.stamps && lane == 0) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&a.stamps[k], acc_cyc[k]);
+        atomicAdd(&a.stamps[4], static_cast<unsigned long long>(acc_cnt[0]));
+        atomicAdd(&a.stamps[5], static_cast<unsigned long long>(acc_cnt[1]));
+        atomicAdd(&a.stamps[8], static_cast<unsigned long long>(acc_cnt[2]));
+        atomicAdd(&a.stamps[9], static_cast<unsigned long long>(acc_cnt[3]));
+        atomicAdd(&a.stamps[10], static_cast<unsigned long long>(acc_cnt[4]));
+    }
+#endif
 }
 
 // ================================================================================================
