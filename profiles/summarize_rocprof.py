@@ -46,19 +46,25 @@ def pmc(path):
     return agg
 
 
+def newest(pattern):
+    """gpurun merges a pass's files into what an earlier session with the same tag left behind: keep the latest run's only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def main():
     src, tag, rnd, scene, variant = sys.argv[1:6]
     n_pixels = int(sys.argv[6]) if len(sys.argv) > 6 else 1920 * 1080
     here = os.path.dirname(os.path.abspath(__file__))
     base = os.path.join(src, f"prof_{tag}_")
-    stats = glob.glob(base + "stats/*/*_kernel_stats.csv")
+    stats = newest(base + "stats/*/*_kernel_stats.csv")
     if stats:
         shutil.copy(stats[0], os.path.join(here, f"{rnd}_kernel_stats_{scene}_{variant}.csv"))
     line = json.load(open(base + "stats.json"))
     json.dump(line, open(os.path.join(here, f"{rnd}_bench_line_{scene}_{variant}.json"), "w"), indent=1)
     out = {}
     for d in ("fetch", "write", "sq", "sq2", "tcc", "tcp", "ta", "ta2"):
-        for p in glob.glob(base + d + "/*/*_counter_collection.csv"):
+        for p in newest(base + d + "/*/*_counter_collection.csv"):
             for k, counters in pmc(p).items():
                 for c, v in counters.items():
                     out.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "max": max(v), "sum": sum(v)}

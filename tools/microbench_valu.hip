@@ -20,10 +20,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct Stamp { unsigned long long cycles, real, r0, r1; };
-typedef float v4f __attribute__((ext_vector_type(4))); // a 128-bit VGPR tuple inline asm can name
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2))); // a 128-bit VGPR tuple inline asm can name
 
 enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW,
-            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, N_KINDS };
+            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, PKFMA, FMAMIX, PERM, MINU, N_KINDS };
 
 // one instruction of the class on register x (a, b: loop-invariant VGPRs; m: an SGPR pair holding a lane mask)
 #define I_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
@@ -49,6 +50,10 @@ enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, 
 #define I_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
 #define I_CNDVCC(x) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : )
 #define I_MINE64(x) asm volatile("v_min_f32_e64 %0, %0, |%1|" : "+v"(x) : "v"(a))
+#define I_PKFMA(k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(y[k]) : "v"(ya), "v"(yb))
+#define I_FMAMIX(x) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(a), "v"(b))
+#define I_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_MINU(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(a))
 #define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc")
 
 #define REP16(OP) OP(x[0]); OP(x[1]); OP(x[2]); OP(x[3]); OP(x[4]); OP(x[5]); OP(x[6]); OP(x[7]); OP(x[8]); OP(x[9]); OP(x[10]); OP(x[11]); OP(x[12]); OP(x[13]); OP(x[14]); OP(x[15])
@@ -61,6 +66,9 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = fa + static_cast<float>((threadIdx.x * 16 + k) & 1023) * 1e-3f;
     float a = fa, b = fb;
+    v2f y[8], ya = {fa, fb}, yb = {fb, fa};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = v2f{x[2 * k], x[2 * k + 1]};
     unsigned long long m = 0x5555aaaa3333ccccull, m2 = 0;
     uint32_t sc = 0;
     uint32_t addr = (threadIdx.x * 37u & 255u) * 64u; // per-lane node pair, 64 B apart
@@ -94,6 +102,13 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
         if (KIND == ANDOR) { REP16(I_ANDOR); REP16(I_ANDOR); REP16(I_ANDOR); REP16(I_ANDOR); }
         if (KIND == CNDVCC) { REP16(I_CNDVCC); REP16(I_CNDVCC); REP16(I_CNDVCC); REP16(I_CNDVCC); }
         if (KIND == MINE64) { REP16(I_MINE64); REP16(I_MINE64); REP16(I_MINE64); REP16(I_MINE64); }
+        if (KIND == PKFMA) { // 64 packed FMAs (two fp32 FMAs each) on 8 register pairs
+#pragma unroll
+            for (int k = 0; k < 64; ++k) I_PKFMA(k & 7);
+        }
+        if (KIND == FMAMIX) { REP16(I_FMAMIX); REP16(I_FMAMIX); REP16(I_FMAMIX); REP16(I_FMAMIX); }
+        if (KIND == PERM) { REP16(I_PERM); REP16(I_PERM); REP16(I_PERM); REP16(I_PERM); }
+        if (KIND == MINU) { REP16(I_MINU); REP16(I_MINU); REP16(I_MINU); REP16(I_MINU); }
         if (KIND == FMA_DEP) { // ONE dependent chain: latency, not throughput
 #pragma unroll
             for (int k = 0; k < 64; ++k) I_FMA(x[0]);
@@ -206,7 +221,8 @@ template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_o
     }
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool only_new = argc > 1; // any argument: only the classes added last (packed FMA, fma_mix, perm, min_u32)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -215,6 +231,15 @@ int main() {
     CK(hipMalloc(&d_out, sizeof(Stamp) * 4 * cus * 8));
     CK(hipMalloc(&d_sink, 64));
     printf("device: %s, %d CUs; cycles = s_memtime ticks, clock = s_memtime / s_memrealtime x 100 MHz, medians over all waves\n", prop.name, cus);
+    if (only_new) {
+        quick = true;
+        run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);
+        run<PKFMA>("v_pk_fma_f32 (two FMAs per instruction)", 64, d_out, d_sink, cus);
+        run<FMAMIX>("v_fma_mix_f32 (f16 source)", 64, d_out, d_sink, cus);
+        run<PERM>("v_perm_b32", 64, d_out, d_sink, cus);
+        run<MINU>("v_min_u32", 64, d_out, d_sink, cus);
+        return 0;
+    }
     run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);
     run<MINMAX>("v_min_f32 / v_max_f32", 64, d_out, d_sink, cus);
     run<MAX3>("v_max3_f32 / v_min3_f32", 64, d_out, d_sink, cus);
@@ -243,5 +268,9 @@ int main() {
     run<ANDOR>("v_and_or_b32", 64, d_out, d_sink, cus);
     run<CNDVCC>("v_cndmask_b32_e32 (vcc)", 64, d_out, d_sink, cus);
     run<MINE64>("v_min_f32_e64 (abs modifier)", 64, d_out, d_sink, cus);
+    run<PKFMA>("v_pk_fma_f32 (two FMAs per instruction)", 64, d_out, d_sink, cus);
+    run<FMAMIX>("v_fma_mix_f32 (f16 source)", 64, d_out, d_sink, cus);
+    run<PERM>("v_perm_b32", 64, d_out, d_sink, cus);
+    run<MINU>("v_min_u32", 64, d_out, d_sink, cus);
     return 0;
 }

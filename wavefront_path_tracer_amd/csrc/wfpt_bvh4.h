@@ -12,7 +12,7 @@ namespace wfpt {
 
 // Four-wide node, QUANTISED to one 64-byte line: the children's boxes as 8-bit offsets in the frame of their union
 // (origin + q * 2^e per axis), then the child words. A child word is the index of a Node4 (inner child),
-// kLeafFlag | count << 28 | first primitive (leaf child) or kEmptyChild. The traversal of scenes beyond LDS is bound by
+// kLeafFlag | count << 28 | first primitive (leaf child) or kEmptyChild (a leaf of no primitives). The traversal of scenes beyond LDS is bound by
 // the rate of random line fetches (tools/microbench_node_fetch.hip: ~60 G lines/s whatever the record size up to 128 B),
 // so a node should be ONE line: the 128-byte float version cost two L2 requests per visit. The quantised box encloses
 // the true one (the host rounds lower planes down and upper planes up UNDER THE DEVICE'S OWN dequantisation arithmetic,
@@ -29,7 +29,9 @@ struct Node4 {
 };
 static_assert(sizeof(Node4) == 64 && offsetof(Node4, qlo) == 16 && offsetof(Node4, child) == 40 && offsetof(Node4, scale_hi) == 56,
               "a four-wide node is one 64-byte line");
-constexpr uint32_t kLeafFlag = 0x80000000u, kEmptyChild = 0xffffffffu;
+constexpr uint32_t kLeafFlag = 0x80000000u;
+// an absent child: a leaf of no primitives behind an inverted box (qlo = 255, qhi = 0), so the traversal needs no test for it
+constexpr uint32_t kEmptyChild = kLeafFlag;
 constexpr uint32_t kLeafCountShift = 28, kLeafMaxCount = 6, kLeafFirstMask = (1u << kLeafCountShift) - 1u; // count 7 would make an all-ones word possible
 
 // Collapses the binary tree (reference numbering, siblings at (2k, 2k+1)) into quantised four-wide nodes, numbered breadth

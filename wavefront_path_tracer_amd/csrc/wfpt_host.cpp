@@ -302,6 +302,7 @@ bool wfpt::collapse_bvh4(const wfpt_bvh_node *nodes, uint32_t n_nodes, const flo
                 }
                 if (fits) { nd4.exp[ax] = static_cast<uint8_t>(biased); nd4.scale_hi[ax] = static_cast<uint16_t>(biased << 7); break; }
             }
+            for (uint32_t k = n_kids; k < 4; ++k) { nd4.qlo[ax][k] = 255; nd4.qhi[ax][k] = 0; } // absent children: inverted, never entered
         }
         return true;
     };

@@ -215,6 +215,12 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
 #ifndef WFPT_EXP_NO_LEAFBOX
 #define WFPT_EXP_NO_LEAFBOX 0 // 1: leaf boxes are not re-tested with the reference's arithmetic
 #endif
+#ifndef WFPT_VISIT4_PK
+#define WFPT_VISIT4_PK 0 // 1: visit4's plane distances two children at a time with v_pk_fma_f32
+#endif
+#ifndef WFPT_LEAF_LANES
+#define WFPT_LEAF_LANES 8 // refill_kernel: lanes that have to wait at a leaf before the wave runs the leaf code
+#endif
 #ifndef WFPT_STAMPS
 #define WFPT_STAMPS 0 // 1: diagnostic build; the middle bounce launches add up, per wave, the shader cycles (s_memtime) spent in each phase
 #endif
@@ -426,7 +432,8 @@ __device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float o
 //     it is tangent to). A hit found that way is the reference's hit. So if a primitive here WOULD have been accepted, the ray
 //     is handed to the reference's own walk, which decides; if none would, entering or not makes no difference.
 // (If nothing changed, entering or not makes no difference either, and the box is never computed: the common case.)
-template <int PRIM>
+// LAZY_INV: the caller does not keep the exact inverse direction (refill_kernel); it is computed where the box is.
+template <int PRIM, bool LAZY_INV = false>
 __device__ __forceinline__ void visit_leaf(const float4 *geom, uint32_t first, uint32_t count, bool box_untested, float ox, float oy, float oz,
                                            float dx, float dy, float dz, float ix, float iy, float iz, float a, float &nearest, uint32_t &best) {
     float n2 = nearest;
@@ -440,6 +447,7 @@ __device__ __forceinline__ void visit_leaf(const float4 *geom, uint32_t first, u
             float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
             for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
             float tmin, tmax;
+            if (LAZY_INV) { ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; } // invDirection (gr:87, sh:153)
             slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
             enter = !(tmin > tmax || tmax <= 0.0f || tmin > nearest); // ex:179: the box is entered unless one of the three holds
         }
@@ -747,16 +755,32 @@ __device__ __forceinline__ Visit4 visit4(const float4 a, const float4 b, const f
     Visit4 v;
     v.w0 = __float_as_uint(c.z); v.w1 = __float_as_uint(c.w); v.w2 = __float_as_uint(d.x); v.w3 = __float_as_uint(d.y);
     float t[4];
+#if WFPT_VISIT4_PK
+    // two children per instruction: v_pk_fma_f32 issues two fp32 FMAs in the slot of one (tools/microbench_valu.hip)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 sx = {spx, spx}, sy = {spy, spy}, sz = {spz, spz}, bx = {opx, opx}, by = {opy, opy}, bz = {opz, opz};
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        const f2 inx = __builtin_elementwise_fma(f2{ubyte(nx, k), ubyte(nx, k + 1)}, sx, bx), iny = __builtin_elementwise_fma(f2{ubyte(ny, k), ubyte(ny, k + 1)}, sy, by),
+                 inz = __builtin_elementwise_fma(f2{ubyte(nz, k), ubyte(nz, k + 1)}, sz, bz);
+        const f2 outx = __builtin_elementwise_fma(f2{ubyte(fx, k), ubyte(fx, k + 1)}, sx, bx), outy = __builtin_elementwise_fma(f2{ubyte(fy, k), ubyte(fy, k + 1)}, sy, by),
+                 outz = __builtin_elementwise_fma(f2{ubyte(fz, k), ubyte(fz, k + 1)}, sz, bz);
+        const float t_in0 = max_(max_(inx.x, iny.x), inz.x), t_in1 = max_(max_(inx.y, iny.y), inz.y);
+        const float t_out0 = min_(min_(outx.x, outy.x), outz.x), t_out1 = min_(min_(outx.y, outy.y), outz.y);
+        t[k] = (max_(t_in0, 0.0f) <= min_(t_out0, nearest)) ? t_in0 : 2e30f;
+        t[k + 1] = (max_(t_in1, 0.0f) <= min_(t_out1, nearest)) ? t_in1 : 2e30f;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float t_in = max_(max_(fma_(ubyte(nx, k), spx, opx), fma_(ubyte(ny, k), spy, opy)), fma_(ubyte(nz, k), spz, opz));
         const float t_out = min_(min_(fma_(ubyte(fx, k), spx, opx), fma_(ubyte(fy, k), spy, opy)), fma_(ubyte(fz, k), spz, opz));
         t[k] = (max_(t_in, 0.0f) <= min_(t_out, nearest)) ? t_in : 2e30f;
     }
-    v.t0 = v.w0 == kEmptyChild ? 2e30f : t[0];
-    v.t1 = v.w1 == kEmptyChild ? 2e30f : t[1];
-    v.t2 = v.w2 == kEmptyChild ? 2e30f : t[2];
-    v.t3 = v.w3 == kEmptyChild ? 2e30f : t[3];
+#endif
+    // (an absent child has an inverted box, qlo = 255 > qhi = 0 on every axis, so it is not entered; should rounding ever make its
+    // two plane distances meet, its word is a leaf of no primitives: nothing to guard here)
+    v.t0 = t[0]; v.t1 = t[1]; v.t2 = t[2]; v.t3 = t[3];
     order2(v.t0, v.w0, v.t1, v.w1); order2(v.t2, v.w2, v.t3, v.w3); order2(v.t0, v.w0, v.t2, v.w2); order2(v.t1, v.w1, v.t3, v.w3);
     order2(v.t1, v.w1, v.t2, v.w2);
     return v;
@@ -1733,8 +1757,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         // lanes waiting in the inner loop (691 Mrays/s on the 1M-triangle soup), while the leaf code (~80 instructions per
         // triangle) is cheap next to a four-box visit (~180): running it every iteration costs less than the waiting did (1024).
         bool fin = false;
-        const bool was_leaf = alive && (cur & kLeafFlag) != 0;
-        if (alive && !was_leaf) {
+        if (alive && (cur & kLeafFlag) == 0) {
             if (budget-- == 0) {
                 fin = true;
             } else {
@@ -1749,14 +1772,17 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             }
             }
         }
-        if (was_leaf) { // at a leaf child
+        // A lane that has just arrived at a leaf goes on into the leaf code of the same iteration. The leaf code runs when enough
+        // lanes wait at a leaf to be worth the wave's time, or when no lane has a node to visit.
+        const bool at_leaf = alive && !fin && (cur & kLeafFlag) != 0;
+        const bool leaf_round = __popcll(__ballot(at_leaf)) >= WFPT_LEAF_LANES || __ballot(alive && !fin && !at_leaf) == 0;
+        if (at_leaf && leaf_round) { // at a leaf child
             if (budget-- == 0) {
                 fin = true;
             } else {
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-                const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
                 const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
-                visit_leaf<PRIM>(a.scene.prim_geom, first, count, a.scene.root_leaf != 0, r4.ox, r4.oy, r4.oz, dx, dy, dz, ix, iy, iz, aa, nearest, best); // see trace_ray4
+                visit_leaf<PRIM, true>(a.scene.prim_geom, first, count, a.scene.root_leaf != 0, r4.ox, r4.oy, r4.oz, dx, dy, dz, 0.f, 0.f, 0.f, aa, nearest, best); // see trace_ray4
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
