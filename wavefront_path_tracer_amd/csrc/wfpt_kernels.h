@@ -239,7 +239,12 @@ constexpr uint32_t kDenseMiss = 0xffffffffu, kDenseInactive = 0xfffffffeu; // pr
 #ifndef WFPT_REFILL_IDLE
 #define WFPT_REFILL_IDLE 40
 #endif
-constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE; // refill when at least this many lanes of a wave are idle
+#ifndef WFPT_REFILL_IDLE_FIRST
+#define WFPT_REFILL_IDLE_FIRST 32
+#endif
+// refill when at least this many lanes of a wave are idle: what a refill costs (shade: ~550 instructions; generate_rays of the
+// first wavefront: ~250) against the idle lanes the traversal drags along until then
+constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE, kRefillIdleFirst = WFPT_REFILL_IDLE_FIRST;
 
 struct RefillArgs {
     Batch batch;

@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         // ---------------- refill: idle lanes take the next rays (one atomic per group)
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
-        if (more && (n_idle >= kRefillIdle)) {
+        if (more && (n_idle >= (MODE == kBounceFirst ? kRefillIdleFirst : kRefillIdle))) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&a.ctl->ticket, n_idle);
             base = __builtin_amdgcn_readfirstlane(base);
