@@ -394,12 +394,13 @@ def main():
         same_shape = bool(pmc) and pmc.get("samples_in_flight") == min(batch, args.spp)
         hbm_per_launch = (pmc or {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"kernel": stage["kname"],
-                           "bound": ("valu" if args.scene == "shirley" and not args.no_lds_scene else "l1"),
+                           "bound": "valu",
                            "bound_note": ("bound by wave64 VALU issue (LDS-resident BVH, no HBM traffic for the scene); achieved / peak / frac are the "
                                           "HBM figures BASELINE asks for, secondary holds the VALU figures (DESIGN.md section 4)"
                                           if args.scene == "shirley" and not args.no_lds_scene else
-                                          "bound by the L1 -> register path of the per-lane node fetches with VALU issue close behind; "
-                                          "achieved / peak / frac are the HBM figures BASELINE asks for (DESIGN.md section 8)"),
+                                          "wave64 VALU issue at the ceiling of the four-box visit's instruction mix, with the L1 -> register path of the "
+                                          "per-lane node fetches (TA busy ~0.75) and the L2-miss traffic (`traffic`: a 128-byte line per 64-byte node) "
+                                          "close behind; achieved / peak / frac are the HBM figures BASELINE asks for (DESIGN.md section 8)"),
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": round(hbm_per_launch, 1) if (hbm_per_launch and same_shape) else None,
