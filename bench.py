@@ -290,6 +290,33 @@ def main():
             frame = pt.gathered()  # outside the timed region: the frame crosses PCIe only for the dump / the check
     elif world == 1:
         frame = pt.accumulated()
+    gather_check = None
+    if world > 1:
+        # The gather's send / receive legs have no multi-GPU test on the one-GPU boxes this is developed on, so every N > 1 run
+        # checks them itself (untimed): each rank's own slab, band by band, must be what rank 0 holds at those bands' rows.
+        import zlib
+        mine = np.ascontiguousarray(pt.accumulated(), "<f4").reshape(-1, args.width, 3)
+        crc = 0
+        for local, band in enumerate(tiles.bands_of(rank, world, args.height)):
+            n_rows = min(8, args.height - band * 8)
+            crc = zlib.crc32(mine[local * 8:local * 8 + n_rows].tobytes(), crc)
+        crcs = [None] * world
+        dist.all_gather_object(crcs, crc)
+        bad_ranks = []
+        if rank == 0:
+            full = frame.cpu().numpy() if hasattr(frame, "cpu") else np.asarray(frame)
+            full = np.ascontiguousarray(full, "<f4").reshape(args.height, args.width, 3)
+            for r in range(world):
+                c = 0
+                for band in tiles.bands_of(r, world, args.height):
+                    c = zlib.crc32(full[band * 8:min(band * 8 + 8, args.height)].tobytes(), c)
+                if c != crcs[r]:
+                    bad_ranks.append(r)
+        flag = [bad_ranks]
+        dist.broadcast_object_list(flag, src=0)
+        if flag[0]:
+            fail(f"the gathered frame differs from the slabs of rank(s) {flag[0]} ({gather_path})")
+        gather_check = f"every rank's slab equals its bands of the gathered frame (crc32 per rank, {world} ranks)"
     if world == 1 and args.force_rccl:  # the one-rank communicator's assembled frame must be the context's own image
         if not np.array_equal(np.ascontiguousarray(frame).view(np.uint32), np.ascontiguousarray(pt.accumulated()).view(np.uint32)):
             fail("RCCL branch: the gathered frame differs from the accumulated image")
@@ -370,6 +397,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else
                    f"pixel bands of 8 rows over {world} ranks + 1 gather per frame ({gather_path})",
                    "gather": gather_path,
+                   "gather_check": gather_check,
                    "rays_traced": int(rays_total[0])},
     }
     info = W.device_info(gpu_index)

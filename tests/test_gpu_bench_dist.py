@@ -36,6 +36,7 @@ def test_two_rank_rehearsal_equals_single_rank(gpu, tmp_path):
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert key in b
     assert a["config"]["rays_traced"] == b["config"]["rays_traced"]  # the same rays, split over two ranks
+    assert a["config"]["gather_check"] is None and b["config"]["gather_check"].startswith("every rank's slab equals")  # bench's own check of the gather
     assert one.read_bytes() == two.read_bytes()
 
 

@@ -43,8 +43,8 @@ def assemble(slabs, width, height):
 
 def _torch():
     """PyTorch, for the collective and the device-side assembly only. Its ROCm wheel bundles its own HIP runtime under
-    the SONAME libwfpt.so also links, so in one process the first of the two to load serves both, and only "torch
-    first" works: fail with that advice instead of torch's "No HIP GPUs are available"."""
+    the SONAME libwfpt.so also links; the package maps the wheel's copy first (`_agree_on_hip_runtime`), so either load
+    order works. Should a process have mapped another copy by other means, say so instead of torch's "No HIP GPUs"."""
     import sys
     loaded_before = "torch" in sys.modules
     import torch
