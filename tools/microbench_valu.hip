@@ -24,7 +24,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2))); // a 128-bit VGPR tuple inline asm can name
 
 enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW,
-            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, PKFMA, FMAMIX, PERM, MINU, N_KINDS };
+            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, PKFMA, FMAMIX, PERM, MINU, MULLO, MULHI, MAD64, DIVSCALE, DIVFMAS, DIVFIXUP, EXPF, LOGF, READLANE, WRITELANE, LSHLADD64, PKMUL, CVTFU, N_KINDS };
 
 // one instruction of the class on register x (a, b: loop-invariant VGPRs; m: an SGPR pair holding a lane mask)
 #define I_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
@@ -54,6 +54,19 @@ enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, 
 #define I_FMAMIX(x) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(a), "v"(b))
 #define I_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
 #define I_MINU(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_MULHI(x) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define I_MAD64(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(y[k]) : "v"(a), "v"(b) : "vcc")
+#define I_DIVSCALE(x) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x) : "v"(a) : "vcc")
+#define I_DIVFMAS(x) asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b) : "vcc")
+#define I_DIVFIXUP(x) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define I_EXPF(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
+#define I_LOGF(x) asm volatile("v_log_f32 %0, %0" : "+v"(x))
+#define I_READLANE(x) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sc) : "v"(x))
+#define I_WRITELANE(x) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(x) : "s"(sc))
+#define I_LSHLADD64(k) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(y[k]) : "v"(ya))
+#define I_PKMUL(k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[k]) : "v"(ya))
+#define I_CVTFU(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x))
 #define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc")
 
 #define REP16(OP) OP(x[0]); OP(x[1]); OP(x[2]); OP(x[3]); OP(x[4]); OP(x[5]); OP(x[6]); OP(x[7]); OP(x[8]); OP(x[9]); OP(x[10]); OP(x[11]); OP(x[12]); OP(x[13]); OP(x[14]); OP(x[15])
@@ -109,6 +122,24 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
         if (KIND == FMAMIX) { REP16(I_FMAMIX); REP16(I_FMAMIX); REP16(I_FMAMIX); REP16(I_FMAMIX); }
         if (KIND == PERM) { REP16(I_PERM); REP16(I_PERM); REP16(I_PERM); REP16(I_PERM); }
         if (KIND == MINU) { REP16(I_MINU); REP16(I_MINU); REP16(I_MINU); REP16(I_MINU); }
+        if (KIND == MULLO) { REP16(I_MULLO); REP16(I_MULLO); REP16(I_MULLO); REP16(I_MULLO); }
+        if (KIND == MULHI) { REP16(I_MULHI); REP16(I_MULHI); REP16(I_MULHI); REP16(I_MULHI); }
+        if (KIND == DIVSCALE) { REP16(I_DIVSCALE); REP16(I_DIVSCALE); REP16(I_DIVSCALE); REP16(I_DIVSCALE); }
+        if (KIND == DIVFMAS) { REP16(I_DIVFMAS); REP16(I_DIVFMAS); REP16(I_DIVFMAS); REP16(I_DIVFMAS); }
+        if (KIND == DIVFIXUP) { REP16(I_DIVFIXUP); REP16(I_DIVFIXUP); REP16(I_DIVFIXUP); REP16(I_DIVFIXUP); }
+        if (KIND == EXPF) { REP16(I_EXPF); REP16(I_EXPF); REP16(I_EXPF); REP16(I_EXPF); }
+        if (KIND == LOGF) { REP16(I_LOGF); REP16(I_LOGF); REP16(I_LOGF); REP16(I_LOGF); }
+        if (KIND == READLANE) { REP16(I_READLANE); REP16(I_READLANE); REP16(I_READLANE); REP16(I_READLANE); }
+        if (KIND == WRITELANE) { REP16(I_WRITELANE); REP16(I_WRITELANE); REP16(I_WRITELANE); REP16(I_WRITELANE); }
+        if (KIND == CVTFU) { REP16(I_CVTFU); REP16(I_CVTFU); REP16(I_CVTFU); REP16(I_CVTFU); }
+        if (KIND == MAD64 || KIND == LSHLADD64 || KIND == PKMUL) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                if (KIND == MAD64) I_MAD64(k & 7);
+                if (KIND == LSHLADD64) I_LSHLADD64(k & 7);
+                if (KIND == PKMUL) I_PKMUL(k & 7);
+            }
+        }
         if (KIND == FMA_DEP) { // ONE dependent chain: latency, not throughput
 #pragma unroll
             for (int k = 0; k < 64; ++k) I_FMA(x[0]);
@@ -238,6 +269,19 @@ int main(int argc, char **argv) {
         run<FMAMIX>("v_fma_mix_f32 (f16 source)", 64, d_out, d_sink, cus);
         run<PERM>("v_perm_b32", 64, d_out, d_sink, cus);
         run<MINU>("v_min_u32", 64, d_out, d_sink, cus);
+        run<MULLO>("v_mul_lo_u32", 64, d_out, d_sink, cus);
+        run<MULHI>("v_mul_hi_u32", 64, d_out, d_sink, cus);
+        run<MAD64>("v_mad_u64_u32", 64, d_out, d_sink, cus);
+        run<DIVSCALE>("v_div_scale_f32", 64, d_out, d_sink, cus);
+        run<DIVFMAS>("v_div_fmas_f32", 64, d_out, d_sink, cus);
+        run<DIVFIXUP>("v_div_fixup_f32", 64, d_out, d_sink, cus);
+        run<EXPF>("v_exp_f32", 64, d_out, d_sink, cus);
+        run<LOGF>("v_log_f32", 64, d_out, d_sink, cus);
+        run<READLANE>("v_readlane_b32", 64, d_out, d_sink, cus);
+        run<WRITELANE>("v_writelane_b32", 64, d_out, d_sink, cus);
+        run<LSHLADD64>("v_lshl_add_u64", 64, d_out, d_sink, cus);
+        run<PKMUL>("v_pk_mul_f32", 64, d_out, d_sink, cus);
+        run<CVTFU>("v_cvt_f32_u32", 64, d_out, d_sink, cus);
         return 0;
     }
     run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);

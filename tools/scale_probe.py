@@ -1,18 +1,59 @@
-"""What one rank of an N-GPU run does, measured on ONE GPU: a context holding the bands of rank 0 of N, `batch` samples in
-flight; prints ms per sample of the slab and the strong-scaling efficiency against the unsharded frame."""
-import sys, time
-sys.path.insert(0, '/root/repo')
+"""What one rank of an N-GPU run of bench.py does, measured on ONE GPU: a context holding the bands of rank `r` of N
+(pixel-keyed RNG, 64 samples in flight), timed over K frames of 64 samples per pixel exactly as bench.py's step is (reset,
+render); prints ms per frame, the per-rank ceiling of the strong-scaling curve (before the gather and rank imbalance: the
+slowest rank bounds the job, so every rank of N is measured when --all-ranks is given) and the per-stage times.
+
+    python tools/scale_probe.py [--all-ranks] [--frames K]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
 import wavefront_path_tracer_amd as W
-w, h, spp = 1920, 1080, 256
-def run(world, batch):
-    pt = W.shirley_path_tracer(w, h, max_wavefronts=8, rng_mode=W.RNG_PIXEL, tile_rank=0, tile_world=world, batch=batch)
-    pt.render(batch); pt.synchronize()
-    t0 = time.perf_counter(); pt.render(spp); pt.synchronize(); el = time.perf_counter() - t0
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--all-ranks", action="store_true")
+ap.add_argument("--frames", type=int, default=8)
+ap.add_argument("--spp", type=int, default=64)
+args = ap.parse_args()
+w, h = 1920, 1080
+
+
+def run(world, rank):
+    pt = W.shirley_path_tracer(w, h, max_wavefronts=8, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=args.spp)
+    for _ in range(2):
+        pt.reset_progress()
+        pt.render(args.spp)
+    pt.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.frames):
+        pt.reset_progress()
+        pt.render(args.spp)
+    pt.synchronize()
+    el = (time.perf_counter() - t0) / args.frames * 1e3
+    ms = np.zeros(W.STAGE_COUNT)
+    n = np.zeros(W.STAGE_COUNT, np.int64)
+    for _ in range(2):
+        pt.reset_progress()
+        m, l = pt.render_timed(args.spp)
+        ms += m
+        n += l
+    stages = {k: round(float(ms[v]) / 2, 3) for k, v in W.STAGES.items() if n[v]}
     pt.close()
-    return el / spp * 1e3
-base = run(1, 64)  # what bench.py runs at N = 1
-print(f"N=1 batch 64: {base:.4f} ms/sample (batch 32: {run(1, 32):.4f})")
+    return el, stages
+
+
+base, st = run(1, 0)
+print(f"N=1: {base:.3f} ms per {args.spp}-spp frame   stages (ms per frame, event-timed) {st}", flush=True)
 for world in (2, 4, 8):
-    for batch in (32, 64, 128):
-        ms = run(world, batch)
-        print(f"N={world} batch {batch}: {ms:.4f} ms/sample of the slab -> speed-up {base / ms:.2f}x, efficiency {base / ms / world:.2f}", flush=True)
+    ranks = range(world) if args.all_ranks else (0,)
+    worst = 0.0
+    for r in ranks:
+        ms, st = run(world, r)
+        worst = max(worst, ms)
+        print(f"N={world} rank {r}: {ms:.3f} ms per frame of its slab   stages {st}", flush=True)
+    print(f"N={world}: slowest measured rank {worst:.3f} ms -> per-rank ceiling {base / worst:.2f}x (efficiency {base / worst / world:.2f})", flush=True)

@@ -1042,7 +1042,7 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     const wfpt_frame_buffer f{c->width, c->height, 0u, 0u};
     CREATE_HIP(hipMemcpy(&c->ctl->frame, &f, sizeof f, hipMemcpyHostToDevice));
 
-    c->accumulate_grid = std::min<uint32_t>((c->pixel_capacity / 4u + 255u) / 256u, cus * 8u); // one thread per 4 pixels
+    c->accumulate_grid = std::min<uint32_t>((c->pixel_capacity + 255u) / 256u, cus * 32u); // one thread per pixel
     if (c->accumulate_grid == 0) c->accumulate_grid = 1;
     CREATE_HIP(hipStreamSynchronize(c->stream));
 #undef CREATE_HIP

@@ -1849,48 +1849,72 @@ __global__ __launch_bounds__(kExtendThreads) void compact_kernel(CompactArgs a) 
 }
 
 // ================================================================================================
-// accumulate (ac:4-17): pure streaming, 16 B per lane
+// accumulate (ac:4-17): pure streaming, 16 B per lane and sample
 // ================================================================================================
 __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
-    // accumulated += image_0; += image_1; ... in sample order, so a batch gives exactly the sums that
-    // sequential samples (one accumulate dispatch each, pt:362) would. One thread = 4 pixels: 4 x 16 B of each image
-    // slice (float4 per pixel) in, 3 x 16 B of `accumulated` (the reference's stride-12 layout) read and written.
-    const uint32_t n_quads = a.n_pixels / 4u;
-    float4 *acc4 = reinterpret_cast<float4 *>(a.accumulated);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += gridDim.x * blockDim.x) {
-        float4 s0 = acc4[3u * i], s1 = acc4[3u * i + 1u], s2 = acc4[3u * i + 2u];
-        for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-            const float4 *im = reinterpret_cast<const float4 *>(a.image + smp * a.batch.image_stride) + 4u * static_cast<size_t>(i);
-            const float4 p0 = im[0], p1 = im[1], p2 = im[2], p3 = im[3];
-            s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p1.x;
-            s1.x += p1.y; s1.y += p1.z; s1.z += p2.x; s1.w += p2.y;
-            s2.x += p2.z; s2.y += p3.x; s2.z += p3.y; s2.w += p3.z;
+    // accumulated += image_0; += image_1; ... in sample order, so a batch gives exactly the sums that sequential samples (one
+    // accumulate dispatch each, pt:362) would. One thread = one pixel: 16 B of each image slice (float4 per pixel) in, 12 B of
+    // `accumulated` (the reference's stride-12 layout) read and written. Sixteen samples' loads are in flight before the first add:
+    // a band-sharded slab gives a SIMD only a few waves, and with one sample per trip each had one load in flight (1.2 TB/s
+    // on 1/8 of the frame); the adds keep the sample order.
+    const size_t stride4 = a.batch.image_stride / 4u; // a slice is a whole number of float4 pixels
+    const float4 *image4 = reinterpret_cast<const float4 *>(a.image);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_pixels; i += gridDim.x * blockDim.x) {
+        float r = a.accumulated[3u * i], g = a.accumulated[3u * i + 1u], b = a.accumulated[3u * i + 2u];
+        const float4 *im0 = image4 + i;
+        uint32_t smp = 0;
+        for (; smp + 16u <= a.batch.n; smp += 16u) {
+            float4 p[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) p[k] = im0[(smp + k) * stride4];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) { r += p[k].x; g += p[k].y; b += p[k].z; }
         }
-        acc4[3u * i] = s0; acc4[3u * i + 1u] = s1; acc4[3u * i + 2u] = s2;
+        for (; smp + 4u <= a.batch.n; smp += 4u) {
+            float4 p[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) p[k] = im0[(smp + k) * stride4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) { r += p[k].x; g += p[k].y; b += p[k].z; }
+        }
+        for (; smp < a.batch.n; ++smp) {
+            const float4 p = im0[smp * stride4];
+            r += p.x; g += p.y; b += p.z;
+        }
+        a.accumulated[3u * i] = r; a.accumulated[3u * i + 1u] = g; a.accumulated[3u * i + 2u] = b;
     }
-    if (blockIdx.x == 0) {
-        const uint32_t tail = 12u * n_quads + threadIdx.x; // channels of the last n_pixels % 4 pixels
-        if (tail < 3u * a.n_pixels) {
-            const uint32_t px = tail / 3u, ch = tail - 3u * px;
-            float s = a.accumulated[tail];
-            for (uint32_t smp = 0; smp < a.batch.n; ++smp) s += a.image[smp * a.batch.image_stride + 4u * static_cast<size_t>(px) + ch];
-            a.accumulated[tail] = s;
-        }
-        if (a.bookkeeping && threadIdx.x == 0) { // end of a fused batch
-            Control *c0 = a.ctl;
-            for (uint32_t smp = 0; smp < a.batch.n; ++smp) {
-                const Control *c = a.ctl + smp;
-                const uint32_t rows = c->bounce < kMaxRows ? c->bounce : kMaxRows;
-                for (uint32_t b = 0; b < rows; ++b) {
-                    if (c->rows[b][0] == 0) continue;
-                    c0->totals[0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
-                    c0->totals[1] += c->rows[b][1];
-                    c0->totals[2] += c->rows[b][2];
-                    c0->wave_totals[b][0] += static_cast<unsigned long long>(c->rows[b][1]) + c->rows[b][2];
-                    c0->wave_totals[b][1] += c->rows[b][1];
-                    c0->wave_totals[b][2] += c->rows[b][2];
-                }
+    if (blockIdx.x == 0 && a.bookkeeping) { // end of a fused batch: the samples' per-wavefront rows -> the context's totals
+        // one thread per sample and integer sums through LDS (one thread walking samples x rows of global memory took ~0.1 ms,
+        // a fixed cost per frame that a band-sharded rank pays in full)
+        __shared__ unsigned long long s_rows[kMaxRows][2]; // hits, misses per wavefront over the batch
+        for (uint32_t k = threadIdx.x; k < 2u * kMaxRows; k += blockDim.x) (&s_rows[0][0])[k] = 0ull;
+        __syncthreads();
+        for (uint32_t smp = threadIdx.x; smp < a.batch.n; smp += blockDim.x) {
+            const Control *c = a.ctl + smp;
+            const uint32_t rows = c->bounce < kMaxRows ? c->bounce : kMaxRows;
+            for (uint32_t b = 0; b < rows; ++b) {
+                if (c->rows[b][0] == 0) continue;
+                atomicAdd(&s_rows[b][0], static_cast<unsigned long long>(c->rows[b][1]));
+                atomicAdd(&s_rows[b][1], static_cast<unsigned long long>(c->rows[b][2]));
             }
+        }
+        __syncthreads();
+        Control *c0 = a.ctl;
+        if (threadIdx.x < kMaxRows) {
+            const uint32_t b = threadIdx.x;
+            const unsigned long long h = s_rows[b][0], m = s_rows[b][1];
+            if (h + m) {
+                c0->wave_totals[b][0] += h + m;
+                c0->wave_totals[b][1] += h;
+                c0->wave_totals[b][2] += m;
+            }
+        }
+        if (threadIdx.x == 0) {
+            unsigned long long h = 0, m = 0;
+            for (uint32_t b = 0; b < kMaxRows; ++b) { h += s_rows[b][0]; m += s_rows[b][1]; }
+            c0->totals[0] += h + m;
+            c0->totals[1] += h;
+            c0->totals[2] += m;
             c0->totals[3] += a.batch.n;
             c0->samples += a.batch.n;
             c0->ticket = 0; // the fused loop's last bounce launch drew tickets after the last scan
