@@ -174,3 +174,79 @@ def close_pairs_scene(orc):
     sp["material_idx"] = np.arange(len(sp)) % 3
     sp["material_type"] = np.arange(len(sp)) % 3
     return sp, mt
+
+
+def adversarial_mesh(tris):
+    """Mutates a TRIANGLE array (the same way for oracle and product) into a mesh made for the edges of the traversal argument:
+    exact duplicates (two hits at bit-equal distances: the visit order decides, extend.wgsl:190-207), triangles that share an
+    edge, and axis-aligned triangles whose boxes have no thickness."""
+    n = len(tris)
+    for k in range(0, min(200, n - 1), 2):
+        tris["v0"][k + 1], tris["e1"][k + 1], tris["e2"][k + 1] = tris["v0"][k], tris["e1"][k], tris["e2"][k]
+    for k in range(200, min(300, n - 1), 2):  # the second triangle completes the parallelogram: the diagonal is shared
+        tris["v0"][k + 1] = tris["v0"][k] + tris["e1"][k] + tris["e2"][k]
+        tris["e1"][k + 1], tris["e2"][k + 1] = -tris["e1"][k], -tris["e2"][k]
+    for k in range(300, min(380, n)):
+        ax = k % 3
+        tris["e1"][k, ax] = 0.0
+        tris["e2"][k, ax] = 0.0
+    return tris
+
+
+def adversarial_rays_mesh(W, tris, nodes, n_max):
+    """Rays for a triangle mesh: at vertices, edge midpoints and centroids head-on and axis-parallel, in the planes of the boxes
+    of flat triangles, along box edges of leaves and inner nodes, and a few ulp around each of them."""
+    rays = []
+    axes = np.eye(3, dtype=np.float32)
+
+    def add(o, d):
+        rays.append((np.asarray(o, np.float32), np.asarray(d, np.float32)))
+
+    rng = np.random.default_rng(7)
+    for k in range(min(len(tris), n_max // 40)):
+        a = tris["v0"][k].astype(np.float32)
+        b = (a + tris["e1"][k]).astype(np.float32)
+        c = (a + tris["e2"][k]).astype(np.float32)
+        nrm = np.cross(tris["e1"][k], tris["e2"][k]).astype(np.float32)
+        ln = np.float32(np.linalg.norm(nrm))
+        nrm = nrm / ln if ln > 0 else axes[k % 3]
+        for p in (a, b, c, (a + b) * np.float32(0.5), (b + c) * np.float32(0.5), (a + b + c) / np.float32(3.0)):
+            add(p + nrm * np.float32(4.0), -nrm)                       # head-on along the normal
+            ax = int(np.argmax(np.abs(nrm)))
+            o = p.copy()
+            o[ax] += np.float32(5.0)
+            add(o, -axes[ax])                                            # axis-parallel: two infinite inverses
+        lo, hi = np.minimum(np.minimum(a, b), c), np.maximum(np.maximum(a, b), c)
+        for ax in range(3):                                              # in the planes of the triangle's own box
+            t_ax = (ax + 1) % 3
+            for plane in (lo[ax], hi[ax]):
+                o = (lo + hi) * np.float32(0.5)
+                o[ax] = plane
+                o[t_ax] = lo[t_ax] - np.float32(2.0)
+                add(o, axes[t_ax])
+                o2 = o.copy()
+                o2[ax] = next_ulp(plane, int(rng.integers(-2, 3)))
+                add(o2, axes[t_ax])
+    for i, nd in enumerate(nodes[: n_max // 60]):
+        if i == 1:
+            continue
+        lo, hi = nd["aabb_min"], nd["aabb_max"]
+        c = (lo + hi) * np.float32(0.5)
+        for ax in range(3):
+            o = c.copy()
+            o[ax] = hi[ax] + np.float32(3.0)
+            add(o, -axes[ax])
+            e = c.copy()
+            e[ax] = hi[ax]
+            e[(ax + 1) % 3] = lo[(ax + 1) % 3] - np.float32(2.0)
+            add(e, axes[(ax + 1) % 3])
+    rays = rays[:n_max]
+    out = np.zeros(len(rays), W.RAY)
+    for k, (o, d) in enumerate(rays):
+        out["origin"][k, :3] = o
+        out["origin"][k, 3] = 1.0
+        out["direction"][k, :3] = d
+    with np.errstate(all="ignore"):
+        out["inv_direction"] = (np.float32(1.0) / out["direction"][:, :3]).astype("<f4")
+    out["pixel_idx"] = np.arange(len(out), dtype="<u4") % 1024
+    return out

@@ -10,8 +10,9 @@ import numpy as np
 import pytest
 
 from conftest import assert_bit_equal
-from helpers import (adversarial_rays as _adversarial_rays, close_pairs_scene as _close_pairs_scene, inputs_for, make_mesh_oracle,
-                     make_mesh_tracer, make_oracle, make_tracer, mesh_inputs)
+from helpers import (adversarial_mesh as _adversarial_mesh, adversarial_rays as _adversarial_rays, adversarial_rays_mesh as _adversarial_rays_mesh,
+                     close_pairs_scene as _close_pairs_scene, inputs_for, make_mesh_oracle, make_mesh_tracer, make_oracle, make_tracer,
+                     mesh_inputs)
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -89,6 +90,50 @@ def test_adversarial_rays_against_the_oracle(gpu, orc, scene, exact):
     assert hits > n // 10 and misses > n // 50
     assert_bit_equal(pt.hits(hits), o.hits(hits).view(W.HIT), f"hit queue of the adversarial rays ({scene}, exact={exact})")
     assert_bit_equal(pt.misses(misses), o.misses(misses), "miss queue of the adversarial rays")
+    pt.close(); o.close()
+
+
+@pytest.mark.parametrize("where", ["lds", "hbm"])
+@pytest.mark.parametrize("exact", [False, True])
+def test_adversarial_rays_on_a_mesh(gpu, orc, where, exact):
+    """The same for triangles (a build extension; the oracle is the only checker): a mesh with exact duplicates (bit-equal
+    distances: the visit order decides), shared edges and triangles whose boxes have no thickness; rays at vertices, edge
+    midpoints and centroids, axis-parallel, in the planes of triangle boxes and along node-box edges. Default walk (conservative
+    inner boxes / quantised four-wide nodes + exact leaf test + hand-over) and the reference's walk, LDS-resident and from HBM."""
+    W = gpu
+    w, h, n_tri = 128, 64, 1200
+    tris, mt = orc.scene_random_mesh(n_tri, 1)
+    tris["e1"] *= np.float32(12.0); tris["e2"] *= np.float32(12.0)
+    _adversarial_mesh(tris)
+    tris_o, nodes = orc.build_bvh_triangles(tris, 32)
+    cam, ip, vw = orc.mesh_camera(w, h)
+    o = orc.Oracle(w, h, np.zeros(1, orc.SPHERE), mt, nodes, cam, ip, vw, triangles=tris_o)
+    scene = W.Scene.random_mesh(n_tri, 1)
+    scene.triangles["e1"] *= np.float32(12.0); scene.triangles["e2"] *= np.float32(12.0)
+    _adversarial_mesh(scene.triangles)
+    cc = W.CameraController(W.Camera((0.0, 0.0, 30.0), (0.0, 0.0, 0.0)), 40.0, 0.0, 10.0, 0.1, 100.0)
+    flags = (W.FLAG_EXACT_TRAVERSAL if exact else 0) | (W.FLAG_NO_LDS_SCENE if where == "hbm" else 0)
+    pt = W.PathTracer(scene, W.RenderParameters(cc, (w, h)), mesh_bins=32, flags=flags)
+    assert_bit_equal(pt.bvh_tree.nodes, nodes.view(W.BVH_NODE), "host BVH of the adversarial mesh")
+    rays = _adversarial_rays_mesh(W, tris_o, nodes, w * h)
+    n = len(rays)
+    assert n > 3000
+    pt.set_frame(W.GPUFrameBuffer.new(w, h, 1)); o.set_frame(1, 0)
+    pt.write_rays(rays); o.write_rays(rays.view(orc.RAY))
+    pt.set_counters([0, 0, n]); o.set_counters([0, 0, n])
+    ext = W.workgroup_size_64(n)
+    pt.extend_kernel.run(ext); o.extend(*ext)
+    c = o.counters()
+    assert np.array_equal(pt.read_counters()[:3], c[:3]), f"{pt.read_counters()[:3]} vs {c[:3]}"
+    misses, hits = int(c[0]), int(c[1])
+    assert hits > n // 10 and misses > n // 50
+    assert_bit_equal(pt.hits(hits), o.hits(hits).view(W.HIT), f"hit queue of the adversarial mesh rays ({where}, exact={exact})")
+    assert_bit_equal(pt.misses(misses), o.misses(misses), "miss queue of the adversarial mesh rays")
+    # and a short render of the same mesh through the device-resident loop
+    want = o.render(2)
+    pt.reset_progress()
+    pt.render(2)
+    assert_bit_equal(pt.accumulated(), want, f"adversarial mesh image ({where}, exact={exact})")
     pt.close(); o.close()
 
 
