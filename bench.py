@@ -223,6 +223,18 @@ def main():
         sys.exit(3)
 
     use_rccl = (world > 1 and not rehearsal) or (world == 1 and args.force_rccl)
+    watchdog = None
+    if use_rccl and world > 1:
+        # a communicator or a first send / receive that never completes would otherwise sit until the caller's own time limit:
+        # say where it stopped and end the rank (the warm-up frames disarm this)
+        import threading
+
+        def stuck():
+            print(f"[bench rank {rank}] the RCCL communicator / first gather did not complete within 300 s; giving up", file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(300.0, stuck)
+        watchdog.daemon = True
+        watchdog.start()
     gather_path = "none" if not (world > 1 or use_rccl) else (
         "gloo through host memory (REHEARSAL)" if not use_rccl else "RCCL send/recv to rank 0 behind the C ABI")
     if use_rccl:
@@ -268,6 +280,8 @@ def main():
     for _ in range(max(args.warmup, 1)):  # also primes (untimed) the captured launch shapes and warms the communicator
         render_frame(args.spp)
     sync()
+    if watchdog is not None:
+        watchdog.cancel()
     rays0 = pt.totals().copy()
     t0 = time.perf_counter()
     frame = None
