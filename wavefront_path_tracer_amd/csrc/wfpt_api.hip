@@ -1568,6 +1568,7 @@ int wfpt_device_info(int device, uint32_t *compute_units, uint32_t *memory_clock
 // ------------------------------------------------------------------ RCCL gather
 // RCCL is opened at run time, so single-GPU users of libwfpt.so carry no dependency on it and a host process that has
 // already loaded a RCCL (e.g. PyTorch's bundled copy) shares that one instead of mapping a second.
+extern "C++" {
 namespace {
 struct Rccl {
     void *handle = nullptr;
@@ -1615,6 +1616,7 @@ int rccl_fail(wfpt_ctx *c, ncclResult_t r, const char *what) {
     } while (0)
 
 } // namespace
+} // extern "C++"
 
 // Root side of the gather: the assembled frame (whole bands) and the staging area the peers' slabs land in, sized for the
 // CURRENT viewport. Called by wfpt_comm_init and again by wfpt_update_render_parameters: a wider, shorter viewport of the same
