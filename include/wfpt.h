@@ -432,9 +432,13 @@ void wfpt_tonemap_rgb8(const float *accumulated, uint32_t n_pixels, uint32_t n_s
  * divide by wfpt_accumulated_samples. Rows are written top to bottom as stored (pixel_idx = x + y*width).
  *   wfpt_save_ppm: binary P6, 8-bit, sqrt(acc / n) exactly like display_shader.wgsl:50-52.
  *   wfpt_save_pfm: binary PF, linear f32 acc / n (PFM stores rows bottom-up, so rows are flipped on write).
- * Contexts created with tile sharding hold only their own bands and are refused. */
+ *   (wfpt_save_png below.) Contexts created with tile sharding hold only their own bands and are refused. */
 int wfpt_save_ppm(wfpt_ctx *ctx, const char *path);
 int wfpt_save_pfm(wfpt_ctx *ctx, const char *path);
+/*   wfpt_save_png: the same 8-bit image as wfpt_save_ppm as a PNG (rows in deflate "stored" blocks: no compression library).
+ *   wfpt_write_png_rgb8: the writer itself, for any width x height RGB8 buffer (e.g. wfpt_tonemap_rgb8 of a gathered frame). */
+int wfpt_save_png(wfpt_ctx *ctx, const char *path);
+int wfpt_write_png_rgb8(const char *path, const uint8_t *rgb, uint32_t width, uint32_t height);
 
 /* ------------------------------------------------------------------ diagnostics */
 /* Runs the device math primitives over arrays (op: 0 sqrt(a), 1 a/b, 2 sin(a), 3 cos(a), 4 pow(a,b),

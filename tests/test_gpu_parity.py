@@ -582,6 +582,10 @@ def test_image_output(gpu, orc, tmp_path):
     assert raw.startswith(head)
     rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(-1, 3)
     assert np.array_equal(rgb, orc.tonemap_rgb8(acc, spp))
+    pt.save_png(tmp_path / "f.png")
+    from test_host_model import _read_png
+    w2, h2, png = _read_png(tmp_path / "f.png")
+    assert (w2, h2) == (w, h) and np.array_equal(png.reshape(-1, 3), rgb)
     pfm = (tmp_path / "f.pfm").read_bytes()
     head = b"PF\n%d %d\n-1.0\n" % (w, h)
     assert pfm.startswith(head)

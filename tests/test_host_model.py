@@ -162,6 +162,42 @@ f 4 1 5 8
 """
 
 
+def _read_png(path):
+    """Minimal PNG reader for 8-bit RGB, filter type 0 rows (what wfpt_write_png_rgb8 writes); checks every chunk's CRC."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        (n,), kind = struct.unpack(">I", raw[pos:pos + 4]), raw[pos + 4:pos + 8]
+        data = raw[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == (zlib.crc32(kind + data) & 0xffffffff), kind
+        chunks.append((kind, data))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, colour, comp, filt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, filt, lace) == (8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 3 * w + 1)  # zlib checks the adler32
+    assert not rows[:, 0].any()
+    return w, h, rows[:, 1:].reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (400, 225), (1920, 37)])
+def test_png_writer(wf, tmp_path, size):
+    """SURVEY 8(f) rank 1 names PNG beside PPM: the writer uses deflate's stored blocks (several per image beyond 64 KB), so
+    any decoder must return the bytes that went in."""
+    w, h = size
+    rgb = np.random.default_rng(w * 31 + h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    path = tmp_path / "f.png"
+    wf.write_png(path, rgb, w, h)
+    w2, h2, back = _read_png(path)
+    assert (w2, h2) == (w, h) and np.array_equal(back, rgb)
+    with pytest.raises(wf.WfptError):
+        wf.write_png(tmp_path / "no_such_dir" / "f.png", rgb, w, h)
+
+
 def test_obj_loader(wf, tmp_path):
     """README.md:25 "start loading in obj files" (build extension): v / f records, polygons fanned, 1-based and
     negative indices, i, i/t, i//n, i/t/n forms."""

@@ -206,6 +206,8 @@ def lib():
         "wfpt_build_info": (C.c_char_p, []),
         "wfpt_save_ppm": (i32, [vp, C.c_char_p]),
         "wfpt_save_pfm": (i32, [vp, C.c_char_p]),
+        "wfpt_save_png": (i32, [vp, C.c_char_p]),
+        "wfpt_write_png_rgb8": (i32, [C.c_char_p, vp, u32, u32]),
         "wfpt_debug_extend_blocks_per_cu": (i32, [i32, u32]),
         "wfpt_debug_read_stamps": (i32, [vp, vp, i32]),
         "wfpt_debug_bvh4": (i32, [vp, u32, vp]),
@@ -269,6 +271,16 @@ def tonemap_rgb8(accumulated, n_samples):
     out = np.zeros(a.size, np.uint8)
     lib().wfpt_tonemap_rgb8(_p(a), a.size // 3, n_samples, _p(out))
     return out.reshape(-1, 3)
+
+
+def write_png(path, rgb8, width, height):
+    """An (height, width, 3) uint8 image as a PNG file (wfpt_write_png_rgb8; no compression library)."""
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    if a.size != 3 * width * height:
+        raise ValueError("rgb8 must hold width * height RGB pixels")
+    st = lib().wfpt_write_png_rgb8(os.fsencode(path), _p(a), width, height)
+    if st != 0:
+        raise WfptError(st, f"cannot write {path}")
 
 
 def selftest_math(op, a, b=None, device=0):
@@ -841,6 +853,10 @@ class PathTracer:
     def save_ppm(self, path):
         """8-bit P6 of sqrt(accumulated / samples), the display shader's tone map (display_shader.wgsl:50-52)."""
         self._check(lib().wfpt_save_ppm(self.handle, os.fsencode(path)))
+
+    def save_png(self, path):
+        """The tone-mapped frame (display_shader.wgsl:50-52) as an 8-bit RGB PNG."""
+        self._check(lib().wfpt_save_png(self.handle, os.fsencode(path)))
 
     def save_pfm(self, path):
         """Linear float32 PFM of accumulated / samples."""

@@ -1761,6 +1761,16 @@ int wfpt_save_ppm(wfpt_ctx *c, const char *path) {
     return ok ? WFPT_OK : fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_ppm: short write");
 }
 
+int wfpt_save_png(wfpt_ctx *c, const char *path) {
+    std::vector<float> acc;
+    if (int r = read_frame(c, acc, "wfpt_save_png"); r != WFPT_OK) return r;
+    if (!path) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_save_png: null path");
+    std::vector<uint8_t> rgb(acc.size());
+    wfpt_tonemap_rgb8(acc.data(), c->n_pixels, c->accumulated_samples, rgb.data());
+    const int st = wfpt_write_png_rgb8(path, rgb.data(), c->width, c->height);
+    return st == WFPT_OK ? WFPT_OK : fail(c, st, std::string("wfpt_save_png: cannot write ") + path);
+}
+
 int wfpt_save_pfm(wfpt_ctx *c, const char *path) {
     std::vector<float> acc;
     if (int r = read_frame(c, acc, "wfpt_save_pfm"); r != WFPT_OK) return r;

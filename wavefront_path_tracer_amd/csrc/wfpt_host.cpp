@@ -631,4 +631,62 @@ void wfpt_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_samples, 
     }
 }
 
+// PNG (8-bit RGB, no interlace) with the pixel rows in deflate "stored" blocks: no compression library, any viewer reads it.
+static uint32_t png_crc(uint32_t crc, const uint8_t *p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+static bool png_chunk(FILE *f, const char type[4], const std::vector<uint8_t> &data) {
+    const uint32_t n = static_cast<uint32_t>(data.size());
+    const uint8_t len[4] = {uint8_t(n >> 24), uint8_t(n >> 16), uint8_t(n >> 8), uint8_t(n)};
+    uint32_t crc = png_crc(0xffffffffu, reinterpret_cast<const uint8_t *>(type), 4);
+    crc = png_crc(crc, data.data(), data.size()) ^ 0xffffffffu;
+    const uint8_t tail[4] = {uint8_t(crc >> 24), uint8_t(crc >> 16), uint8_t(crc >> 8), uint8_t(crc)};
+    return std::fwrite(len, 1, 4, f) == 4 && std::fwrite(type, 1, 4, f) == 4 &&
+           (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) && std::fwrite(tail, 1, 4, f) == 4;
+}
+int wfpt_write_png_rgb8(const char *path, const uint8_t *rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || width == 0 || height == 0) return WFPT_ERR_INVALID_ARGUMENT;
+    const size_t row = 3 * static_cast<size_t>(width);
+    std::vector<uint8_t> raw((row + 1) * height); // every row behind its filter byte (0: none)
+    for (uint32_t y = 0; y < height; ++y) {
+        raw[y * (row + 1)] = 0;
+        std::memcpy(&raw[y * (row + 1) + 1], rgb + y * row, row);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01); // zlib header: deflate, 32 K window, no preset dictionary
+    uint32_t a = 1, b = 0; // adler32 of the raw data
+    for (size_t off = 0; off < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0); // BFINAL, BTYPE = 00 (stored)
+        z.push_back(uint8_t(n)); z.push_back(uint8_t(n >> 8));
+        z.push_back(uint8_t(~n)); z.push_back(uint8_t((~n) >> 8));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = off; i < off + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        off += n;
+    }
+    const uint32_t adler = (b << 16) | a;
+    z.push_back(uint8_t(adler >> 24)); z.push_back(uint8_t(adler >> 16)); z.push_back(uint8_t(adler >> 8)); z.push_back(uint8_t(adler));
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return WFPT_ERR_INVALID_ARGUMENT;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr = {uint8_t(width >> 24), uint8_t(width >> 16), uint8_t(width >> 8), uint8_t(width),
+                                 uint8_t(height >> 24), uint8_t(height >> 16), uint8_t(height >> 8), uint8_t(height),
+                                 8, 2, 0, 0, 0}; // 8 bits per channel, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+    const bool ok = std::fwrite(sig, 1, 8, f) == 8 && png_chunk(f, "IHDR", ihdr) && png_chunk(f, "IDAT", z) && png_chunk(f, "IEND", {});
+    std::fclose(f);
+    return ok ? WFPT_OK : WFPT_ERR_INVALID_ARGUMENT;
+}
+
 } // extern "C"
