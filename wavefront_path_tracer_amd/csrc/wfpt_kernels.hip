@@ -24,6 +24,9 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long mask) {
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// a value every lane of the wave holds alike (read through LDS or with a uniform address): as a scalar, so that what is computed
+// from it (offsets, bounds) runs on the scalar unit instead of 64 lanes
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Pointers with their address space in the TYPE, for code that picks per lane between an LDS copy and global memory: hipcc
 // otherwise folds `if (in_lds) x = lds[i]; else x = global[j];` into a select of two generic pointers and ONE flat load, which
@@ -1141,13 +1144,16 @@ __device__ __forceinline__ float3_ reflect(float3_ r, float3_ n) { // sh:164-166
 
 // sh:71-73: shade's RNG state for hit `h` of a dispatch whose x extent is `gx` workgroups (keyed by the dispatch's
 // global_invocation_id), or keyed by the ray's own pixel (WFPT_RNG_PIXEL).
+// WAVE_H: the wave's lanes hold 64 consecutive hits h of one 64-aligned group (the fused bounce kernel), so the dispatch's workgroup
+// index and its division by gx are scalars.
+template <bool WAVE_H = false>
 __device__ __forceinline__ uint32_t shade_rng(uint32_t rng_mode, uint32_t h, uint32_t gx, uint32_t pixel_idx, wfpt_frame_buffer fb) {
     uint32_t id_x, id_y;
     if (rng_mode == WFPT_RNG_PIXEL) {
         id_y = pixel_idx / fb.width;
         id_x = pixel_idx - id_y * fb.width;
     } else {
-        const uint32_t wg = h >> 6, li = h & 63u;
+        const uint32_t wg = WAVE_H ? uniform(h >> 6) : h >> 6, li = h & 63u;
         const uint32_t wgy = wg / gx;
         id_x = (wg - wgy * gx) * 8u + (li & 7u);
         id_y = wgy * 8u + (li >> 3);
@@ -1348,12 +1354,15 @@ struct HitSource {
     uint32_t capacity, rng_mode, image_width, prim_kind;
     Tiling tile;
 };
-template <bool SCATTER>
+// WAVE_RUN: every lane of the wave shades a hit of the same run of kChunk hits and the same sample (the fused bounce kernel), so the
+// run's segment bounds and the sample's counters are scalars.
+template <bool SCATTER, bool WAVE_RUN = false>
 __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32_t n_hits, wfpt_frame_buffer fb, float &ox, float &oy,
                                           float &oz, float &dx, float &dy, float &dz, uint32_t &pixel_idx) {
-    const uint32_t run = h / kChunk, n_runs = (n_hits + kChunk - 1) / kChunk;
+    const uint32_t run = WAVE_RUN ? uniform(h / kChunk) : h / kChunk, n_runs = (n_hits + kChunk - 1) / kChunk;
     uint32_t lo = s.in_first_seg[s.co + run];
     uint32_t hi = run + 1 < n_runs ? s.in_first_seg[s.co + run + 1] : (umin(s.ctl->seg_n, s.capacity) + kChunk - 1) / kChunk - 1u;
+    if (WAVE_RUN) { lo = uniform(lo); hi = uniform(hi); }
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1u) >> 1;
         if (s.in_hit_base[s.co + mid] <= h) lo = mid; else hi = mid - 1u;
@@ -1367,7 +1376,8 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
     const float4 thr = *px;
     if (SCATTER) {
         const float4 rec0 = s.shade_rec[3u * prim], rec2 = s.shade_rec[3u * prim + 2u];
-        const uint32_t rng = shade_rng(s.rng_mode, h, s.ctl->shade_gx, pixel_idx, fb);
+        const uint32_t gx = WAVE_RUN ? uniform(s.ctl->shade_gx) : s.ctl->shade_gx;
+        const uint32_t rng = shade_rng<WAVE_RUN>(s.rng_mode, h, gx, pixel_idx, fb);
         const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), s.prim_kind);
         ox = ra.x; oy = ra.y; oz = ra.z;
         dx = ext.x; dy = ext.y; dz = ext.z;
@@ -1446,7 +1456,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         atomicAdd(&L.total[1], items_h + items_m); // all items of this launch
     }
     __syncthreads();
-    const uint32_t n_hit_items = L.total[0], n_items = L.total[1];
+    const uint32_t n_hit_items = uniform(L.total[0]), n_items = uniform(L.total[1]);
     // a workgroup's tickets only grow, so the sample of an item is found by walking on from where the previous item was
     uint32_t smp_h = 0, first_h = 0, smp_m = 0, first_m = n_hit_items;
     if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n)
@@ -1463,7 +1473,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         for (uint32_t i = threadIdx.x; i < parent_words; i += kExtendThreads) s_par4[i] = g_par[i];
         __syncthreads();
     }
-    const wfpt_frame_buffer fb0 = a.ctl->frame;
+    wfpt_frame_buffer fb0 = a.ctl->frame; // the same for every lane: kept in scalar registers
+    fb0.width = uniform(fb0.width); fb0.height = uniform(fb0.height); fb0.frame = uniform(fb0.frame); fb0.sample_number = uniform(fb0.sample_number);
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t iter = 0;
 #if WFPT_STAMPS
@@ -1475,17 +1486,17 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         if (item >= n_hit_items) {
             // ---------------- miss_kernel (mk:13-38) for kMissSegsPerItem segments of the previous wavefront's miss queue
-            while (item >= first_m + L.items_m[smp_m]) first_m += L.items_m[smp_m++];
+            while (item >= first_m + uniform(L.items_m[smp_m])) first_m += uniform(L.items_m[smp_m++]);
             const uint32_t smp = smp_m;
             const uint32_t first_seg = (item - first_m) * kMissSegsPerItem;
-            const uint32_t n_segs = (umin(a.ctl[smp].seg_n, a.capacity) + kChunk - 1) / kChunk;
+            const uint32_t n_segs = (uniform(umin(a.ctl[smp].seg_n, a.capacity)) + kChunk - 1) / kChunk;
             const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
             float *image = a.image + smp * a.batch.image_stride;
             // one segment per wave at a time: the eight waves keep eight independent load -> read-modify-write chains in flight
             for (uint32_t k = wave; k < kMissSegsPerItem; k += kExtendWaves) {
                 const uint32_t seg = first_seg + k;
                 if (seg >= n_segs) break;
-                const uint32_t count = a.in_miss[co + seg];
+                const uint32_t count = uniform(a.in_miss[co + seg]);
                 for (uint32_t r = lane; r < count; r += 64u) {
                     const size_t slot = qo + static_cast<size_t>(seg) * kChunk + r;
                     const float dy = a.mq_in.dy()[slot]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
@@ -1501,15 +1512,15 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 }
             }
             __syncthreads(); // L.next[buf] is visible
-            item = L.next[buf];
+            item = uniform(L.next[buf]);
             iter += 1;
             continue;
         }
         WFPT_STAMP(t_item);
-        while (item >= first_h + L.items_h[smp_h]) first_h += L.items_h[smp_h++]; // block-uniform
+        while (item >= first_h + uniform(L.items_h[smp_h])) first_h += uniform(L.items_h[smp_h++]); // block-uniform
         const uint32_t smp = smp_h;
         const uint32_t seg_out = item - first_h;
-        const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : umin(a.ctl[smp].shade_n, a.capacity);
+        const uint32_t n = MODE == kBounceFirst ? umin(n_slots, a.capacity) : uniform(umin(a.ctl[smp].shade_n, a.capacity));
         const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
         float *image = a.image + smp * a.batch.image_stride;
         wfpt_frame_buffer fb = fb0;
@@ -1521,7 +1532,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         uint32_t pixel_idx = 0;
         if (MODE == kBounceFirst) {
             // ---------------- generate_rays (gr:42-91), true-size semantics: lanes outside the image emit nothing
-            const uint32_t workgroup_index = h >> 6, local_index = h & 63u;
+            const uint32_t workgroup_index = uniform(h >> 6), local_index = h & 63u; // one wave = one 8x8 tile of generate_rays
             const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
             const uint32_t id_x = wx * 8u + (local_index & 7u);
             const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
@@ -1536,11 +1547,11 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             // ---------------- shade (sh:56-156) of hit h of the previous wavefront
             const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, image, a.scene.shade_rec, qo, co,
                                 a.capacity, a.rng_mode, a.image_width, a.scene.prim_kind, a.tile};
-            shade_hit<TRACE>(src, h, n, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
+            shade_hit<TRACE, true>(src, h, n, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
         }
         if (!TRACE) {
             __syncthreads();
-            item = L.next[buf];
+            item = uniform(L.next[buf]);
             iter += 1;
             continue;
         }
@@ -1588,7 +1599,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kExtendWaves; ++w) {
-            const uint32_t hc = L.cnt[(buf * 2 + 0) * kExtendWaves + w], mc = L.cnt[(buf * 2 + 1) * kExtendWaves + w];
+            const uint32_t hc = uniform(L.cnt[(buf * 2 + 0) * kExtendWaves + w]), mc = uniform(L.cnt[(buf * 2 + 1) * kExtendWaves + w]);
             hit_before += (w < wave) ? hc : 0u;
             miss_before += (w < wave) ? mc : 0u;
             hit_total += hc;
@@ -1628,7 +1639,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             acc_cnt[2] += w_visits; acc_cnt[3] += w_leaves; acc_cnt[4] += l_visits;
         }
 #endif
-        item = L.next[buf];
+        item = uniform(L.next[buf]);
         iter += 1;
     }
 #if WFPT_STAMPS
@@ -1671,7 +1682,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         s_first[a.batch.n] = total;
     }
     __syncthreads();
-    const uint32_t total = s_first[a.batch.n];
+    const uint32_t total = uniform(s_first[a.batch.n]);
     if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n) a.ctl[threadIdx.x].n_in = umin(n_slots, a.capacity); // pt:313-316
     if (total == 0) return;
     // N1: the first tile_n nodes (breadth-first numbering: the top levels of the four-wide tree, where every ray passes) are
@@ -1682,8 +1693,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         for (uint32_t i = threadIdx.x; i < 4u * tile_n; i += kExtendThreads) tile_w[i] = a.scene.nodes4[i];
         __syncthreads();
     }
-    const wfpt_frame_buffer fb0 = a.ctl->frame;
+    wfpt_frame_buffer fb0 = a.ctl->frame; // the same for every lane: kept in scalar registers
+    fb0.width = uniform(fb0.width); fb0.height = uniform(fb0.height); fb0.frame = uniform(fb0.frame); fb0.sample_number = uniform(fb0.sample_number);
     const uint32_t lane = lane_id();
+    uint32_t smp_cur = 0; // sample of the last group's first ray: a wave's tickets only grow, so the search goes on from there
     Stack4 st;
     st.lds = s_stack;
     st.stride = a.scene.spill_stride;
@@ -1707,10 +1720,11 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             if (lane == 0) base = atomicAdd(&a.ctl->ticket, n_idle);
             base = __builtin_amdgcn_readfirstlane(base);
             more = base + n_idle < total;
+            while (base < total && base >= uniform(s_first[smp_cur + 1])) ++smp_cur; // scalar
             const uint32_t g = base + mbcnt(idle);
             if (!alive && g < total) {
-                smp = 0;
-                while (g >= s_first[smp + 1]) ++smp;
+                smp = smp_cur;
+                while (g >= s_first[smp + 1]) ++smp; // a group rarely straddles samples
                 ray = g - s_first[smp];
                 float *image = a.image + smp * a.batch.image_stride;
                 wfpt_frame_buffer fb = fb0;
