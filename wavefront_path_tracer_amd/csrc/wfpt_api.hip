@@ -981,8 +981,13 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     }
     CREATE_HIP(dmalloc(&c->hit_mem, 3 * nb * c->capacity));
     CREATE_HIP(dmalloc(&c->miss_mem, 3 * nb * c->capacity));
-    c->hq = {c->hit_mem, nb * c->capacity};
-    c->mq = {c->miss_mem, nb * c->capacity};
+    if (nb * c->capacity > 0xffffffffull || nb_all * c->capacity > 0xffffffffull) {
+        fail(nullptr, WFPT_ERR_UNSUPPORTED, "wfpt_create: samples in flight x ray capacity beyond 2^32 queue slots");
+        wfpt_destroy(c);
+        return nullptr;
+    }
+    c->hq.base = c->hit_mem; c->hq.plane = nb * c->capacity;
+    c->mq.base = c->miss_mem; c->mq.plane = nb * c->capacity;
     const size_t n_counts = nb_all * c->n_chunks_max; // the scan's bases serve both paths
     CREATE_HIP(dmalloc(&c->chunk_hits, n_counts));
     CREATE_HIP(dmalloc(&c->chunk_miss, n_counts));
@@ -1005,7 +1010,7 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         for (int k = 0; k < 2; ++k) {
             CREATE_HIP(dmalloc(&c->rec_mem[k], 2 * slots));
             CREATE_HIP(dmalloc(&c->f_miss_mem[k], 3 * slots));
-            c->f_mq[k] = {c->f_miss_mem[k], slots};
+            c->f_mq[k].base = c->f_miss_mem[k]; c->f_mq[k].plane = slots;
             CREATE_HIP(dmalloc(&c->f_chunk_hits[k], counts));
             CREATE_HIP(dmalloc(&c->f_chunk_miss[k], counts));
             CREATE_HIP(hipMemsetAsync(c->f_chunk_hits[k], 0, sizeof(uint32_t) * counts, c->stream));

@@ -32,6 +32,14 @@ constexpr int kMaxBatchClassic = 64; // ... by the stage kernels one by one (WFP
 
 // SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed. The seven planes of a
 // slice sit `cap` elements apart behind one base pointer (3 SGPRs per queue in a kernel instead of 14).
+// An element count that fits 32 bits but is used in 64-bit address arithmetic: kept as ONE scalar register in the kernels' argument
+// blocks (a size_t costs two, and the fused kernels spill scalar registers to vector lanes), widened where it is used.
+struct Stride32 {
+    uint32_t v;
+    __host__ __device__ operator size_t() const { return v; }
+    __host__ __device__ Stride32 &operator=(size_t x) { v = static_cast<uint32_t>(x); return *this; }
+};
+
 struct RayQueue {
     float *base;
     uint32_t cap;
@@ -48,17 +56,17 @@ struct RayQueue {
 // segment-compacted. Three planes `plane` elements apart behind one base pointer each.
 struct HitQueue {
     uint32_t *base;
-    size_t plane; // elements between planes (= samples in flight * capacity)
+    Stride32 plane; // elements between planes (= samples in flight * capacity)
     __host__ __device__ float *t() const { return reinterpret_cast<float *>(base); }
-    __host__ __device__ uint32_t *prim() const { return base + plane; }
-    __host__ __device__ uint32_t *ridx() const { return base + 2u * plane; }
+    __host__ __device__ uint32_t *prim() const { return base + static_cast<size_t>(plane); }
+    __host__ __device__ uint32_t *ridx() const { return base + 2u * static_cast<size_t>(plane); }
 };
 struct MissQueue {
     uint32_t *base;
-    size_t plane;
+    Stride32 plane;
     __host__ __device__ uint32_t *ridx() const { return base; }
-    __host__ __device__ float *dy() const { return reinterpret_cast<float *>(base + plane); }
-    __host__ __device__ uint32_t *pixel() const { return base + 2u * plane; }
+    __host__ __device__ float *dy() const { return reinterpret_cast<float *>(base + static_cast<size_t>(plane)); }
+    __host__ __device__ uint32_t *pixel() const { return base + 2u * static_cast<size_t>(plane); }
 };
 
 // Device-resident control block. `counters` is the reference's counter_buffer (extend.wgsl:41).
@@ -143,10 +151,10 @@ struct Tiling {
 struct Batch {
     uint32_t n;            // samples in this launch (1 for the stage API)
     uint32_t ctl_stride;   // u32 words between Control blocks
-    size_t ray_stride;     // floats between ray-queue slices (7 * capacity)
-    size_t queue_stride;   // elements between hit / miss queue slices (capacity)
-    size_t chunk_stride;   // elements between per-segment count arrays
-    size_t image_stride;   // floats between image slices (a slice holds one float4 per pixel)
+    Stride32 ray_stride;   // floats between ray-queue slices (7 * capacity)
+    Stride32 queue_stride; // elements between hit / miss queue slices (capacity)
+    Stride32 chunk_stride; // elements between per-segment count arrays
+    Stride32 image_stride; // floats between image slices (a slice holds one float4 per pixel)
 };
 
 struct GenerateArgs {

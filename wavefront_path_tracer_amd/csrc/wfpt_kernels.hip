@@ -897,7 +897,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         __syncthreads();
     }
 
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6); // (a scalar: what is selected or summed per wave below runs on the scalar unit)
     uint32_t iter = 0;
     while (item < n_items) {
         const uint32_t buf = iter & 1u;
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     if (a.first_seg) a.first_seg += sample * a.batch.chunk_stride;
     const uint32_t n = umin(a.n_in[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit);
     const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6); // (a scalar: what is selected or summed per wave below runs on the scalar unit)
     uint32_t carry_h = 0, carry_m = 0;
     for (uint32_t base = 0; base < n_chunks; base += kScanThreads) {
         const uint32_t i = base + threadIdx.x;
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     }
     wfpt_frame_buffer fb0 = a.ctl->frame; // the same for every lane: kept in scalar registers
     fb0.width = uniform(fb0.width); fb0.height = uniform(fb0.height); fb0.frame = uniform(fb0.frame); fb0.sample_number = uniform(fb0.sample_number);
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6); // (a scalar: what is selected or summed per wave below runs on the scalar unit)
     uint32_t iter = 0;
 #if WFPT_STAMPS
     unsigned long long acc_cyc[4] = {0, 0, 0, 0};
@@ -1830,7 +1830,7 @@ __global__ __launch_bounds__(kExtendThreads) void compact_kernel(CompactArgs a) 
     const uint32_t prim = __float_as_uint(rb.w);
     const bool hit = prim < kDenseInactive, miss = prim == kDenseMiss;
     const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6); // (a scalar: what is selected or summed per wave below runs on the scalar unit)
     if (lane == 0) {
         s_cnt[0][wave] = static_cast<uint32_t>(__popcll(hit_mask));
         s_cnt[1][wave] = static_cast<uint32_t>(__popcll(miss_mask));
@@ -1839,7 +1839,7 @@ __global__ __launch_bounds__(kExtendThreads) void compact_kernel(CompactArgs a) 
     uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kExtendWaves; ++w) {
-        const uint32_t hc = s_cnt[0][w], mc = s_cnt[1][w];
+        const uint32_t hc = uniform(s_cnt[0][w]), mc = uniform(s_cnt[1][w]);
         hit_before += (w < wave) ? hc : 0u;
         miss_before += (w < wave) ? mc : 0u;
         hit_total += hc;
