@@ -903,9 +903,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         const uint32_t buf = iter & 1u;
         if (threadIdx.x == 0) s_next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         uint32_t smp = 0;
-        while (item >= s_first[smp + 1]) ++smp; // at most batch.n - 1 steps, block-uniform
-        const uint32_t chunk = item - s_first[smp];
-        const uint32_t n = s_rays[smp];
+        while (item >= uniform(s_first[smp + 1])) ++smp; // at most batch.n - 1 steps, block-uniform (scalars: uniform())
+        const uint32_t chunk = item - uniform(s_first[smp]);
+        const uint32_t n = uniform(s_rays[smp]);
         const RayQueue q = slice(a.q, smp * a.batch.ray_stride);
         const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
 
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kExtendWaves; ++w) {
-            const uint32_t h = s_misc[(buf * 2 + 0) * kExtendWaves + w], m = s_misc[(buf * 2 + 1) * kExtendWaves + w];
+            const uint32_t h = uniform(s_misc[(buf * 2 + 0) * kExtendWaves + w]), m = uniform(s_misc[(buf * 2 + 1) * kExtendWaves + w]);
             hit_before += (w < wave) ? h : 0u;
             miss_before += (w < wave) ? m : 0u;
             hit_total += h;
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
                 uint32_t before = 0, total = 0;
 #pragma unroll
                 for (uint32_t w = 0; w < kExtendWaves; ++w) {
-                    const uint32_t cnt = s_mat[(buf * 3 + m) * kExtendWaves + w];
+                    const uint32_t cnt = uniform(s_mat[(buf * 3 + m) * kExtendWaves + w]);
                     before += (w < wave) ? cnt : 0u;
                     total += cnt;
                 }
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
                 if (threadIdx.x == 0) a.chunk_mat[m * a.chunk_mat_mstride + co + chunk] = total;
             }
         }
-        item = s_next[buf];
+        item = uniform(s_next[buf]);
         iter += 1;
     }
 }
@@ -1241,8 +1241,8 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
     const uint32_t *chunk_mat = a.chunk_mat + mclass * a.chunk_mat_mstride + sample * a.batch.chunk_stride;
     if (a.count_out && !split && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->counters[2] += n_hits; // sh:155
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint32_t count = split ? chunk_mat[chunk] : a.chunk_hits[chunk];
-        const uint32_t base = a.chunk_hit_base[chunk];
+        const uint32_t count = uniform(split ? chunk_mat[chunk] : a.chunk_hits[chunk]); // block-uniform: scalars
+        const uint32_t base = uniform(a.chunk_hit_base[chunk]);
         if (base >= n_hits) break; // bases ascend with the segment index
         // Software-pipelined walk: the queue entry of the NEXT iteration is loaded before this iteration's
         // dependent gathers, so each hit costs two dependent memory levels instead of three.
