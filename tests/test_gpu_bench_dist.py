@@ -66,7 +66,28 @@ def test_bench_starts_its_own_ranks(gpu):
         assert r.returncode == 0, r.stderr[-3000:]
         line = last_json_line(r.stdout)
         assert line["n_gpus"] == 2 and "RCCL" in line["config"]["gather"]
+        assert line["config"]["gather_check"].startswith("every rank's slab equals")
     else:
         assert r.returncode != 0
         assert "RCCL communicator could not be built" in r.stderr, r.stderr[-3000:]
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no number from a run that did not shard over GPUs
+
+
+def test_two_gpus_over_rccl_equal_one_gpu(gpu, tmp_path):
+    """Where the box has two GPUs: the frame of two ranks, one GPU each, gathered by ncclSend / ncclRecv behind the C ABI, is the
+    single-GPU frame of the pixel-keyed RNG mode byte for byte (the legs a one-GPU box cannot run; skipped there)."""
+    if gpu.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    one, two = tmp_path / "n1.ppm", tmp_path / "n2.ppm"
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, "--rng-mode", "pixel", "--dump", str(one)],
+                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *COMMON, "--dump", str(two)],
+                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    b = last_json_line(r2.stdout)
+    assert b["n_gpus"] == 2 and "RCCL" in b["config"]["gather"] and b["config"]["rng_mode"] == "pixel"
+    assert one.read_bytes() == two.read_bytes()
