@@ -1241,8 +1241,8 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
     const uint32_t *chunk_mat = a.chunk_mat + mclass * a.chunk_mat_mstride + sample * a.batch.chunk_stride;
     if (a.count_out && !split && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->counters[2] += n_hits; // sh:155
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint32_t count = uniform(split ? chunk_mat[chunk] : a.chunk_hits[chunk]); // block-uniform: scalars
-        const uint32_t base = uniform(a.chunk_hit_base[chunk]);
+        const uint32_t count = split ? chunk_mat[chunk] : a.chunk_hits[chunk];
+        const uint32_t base = a.chunk_hit_base[chunk];
         if (base >= n_hits) break; // bases ascend with the segment index
         // Software-pipelined walk: the queue entry of the NEXT iteration is loaded before this iteration's
         // dependent gathers, so each hit costs two dependent memory levels instead of three.
