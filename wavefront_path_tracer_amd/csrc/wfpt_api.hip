@@ -426,7 +426,9 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
                               [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par), c->stream); }));
             if (b + 1 < c->p.max_wavefronts) {
                 WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] { return launch_miss(fused_miss_args(c, par, nb), consumer_grid(c, nb), c->stream); }));
-                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_refill(refill_args(c, par, nb), kBounceMiddle, grid, c->stream); }));
+                if (WFPT_PRESHADE) // shade at full waves into the dense array, then the traversal refills from it
+                    WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] { return launch_shade_rays(refill_args(c, par, nb), c->n_chunks_max, c->stream); }));
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_refill(refill_args(c, par, nb), kBounceMiddle, grid, c->stream, WFPT_PRESHADE != 0); }));
             } else {
                 WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceLast, bounce_grid(c, nb), c->stream); }));
             }

@@ -248,11 +248,21 @@ constexpr uint32_t kDenseMiss = 0xffffffffu, kDenseInactive = 0xfffffffeu; // pr
 #define WFPT_REFILL_IDLE 40
 #endif
 #ifndef WFPT_REFILL_IDLE_FIRST
-#define WFPT_REFILL_IDLE_FIRST 32
+#define WFPT_REFILL_IDLE_FIRST 16
 #endif
 // refill when at least this many lanes of a wave are idle: what a refill costs (shade: ~550 instructions; generate_rays of the
 // first wavefront: ~250) against the idle lanes the traversal drags along until then
-constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE, kRefillIdleFirst = WFPT_REFILL_IDLE_FIRST;
+#ifndef WFPT_TICKET_BLOCK
+#define WFPT_TICKET_BLOCK 64
+#endif
+constexpr uint32_t kTicketBlock = WFPT_TICKET_BLOCK; // ray indices a wave of the refill traversal reserves per atomic
+#ifndef WFPT_REFILL_IDLE_PRESHADED
+#define WFPT_REFILL_IDLE_PRESHADED 24
+#endif
+#ifndef WFPT_PRESHADE
+#define WFPT_PRESHADE 1 // middle wavefronts of the refill traversal: shade in a kernel of its own (shade_rays_kernel), rays through the dense array
+#endif
+constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE, kRefillIdleFirst = WFPT_REFILL_IDLE_FIRST, kRefillIdlePreshaded = WFPT_REFILL_IDLE_PRESHADED;
 
 struct RefillArgs {
     Batch batch;
@@ -325,7 +335,8 @@ hipError_t launch_generate(const GenerateArgs &a, hipStream_t s);
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s); // one workgroup per sample
 hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s);
-hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s);
+hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s, bool preshaded = false);
+hipError_t launch_shade_rays(const RefillArgs &a, uint32_t n_chunks, hipStream_t s);
 hipError_t launch_compact(const CompactArgs &a, uint32_t n_chunks, hipStream_t s);
 hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks);
 uint32_t bounce_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene);

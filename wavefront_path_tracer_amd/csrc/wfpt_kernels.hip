@@ -1662,7 +1662,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
 #ifndef WFPT_REFILL_MIN_WAVES
 #define WFPT_REFILL_MIN_WAVES 8
 #endif
-template <int MODE, int PRIM>
+// PRESHADED (middle wavefronts): the extension rays were produced by shade_rays_kernel -- shade at 64 lanes per wave instead of at
+// the 24-40 idle lanes of a refill -- and wait in the dense array at their ray's slot, (o | pixel), (d | -); a lane that takes ray g
+// reads its 32 bytes, traces, and leaves the result in the same slot. A refill then costs next to nothing, so waves refill early.
+template <int MODE, int PRIM, bool PRESHADED = false>
 __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_kernel(RefillArgs a) {
     extern __shared__ float4 lds[];
     uint32_t *s_n = reinterpret_cast<uint32_t *>(lds);   // [kMaxBatch] rays of this wavefront per sample
@@ -1710,19 +1713,42 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     // keeps the hot loop's registers free of them; more state here meant scratch spills inside the loop)
     float dx = 0, dy = 0, dz = 0, nearest = 1e30f;
     Ray4 r4 = {0, 0, 0, 0, 0, 0};
-    bool more = true; // rays left at the cursor (wave-uniform)
+    bool more = true; // rays left at the global cursor (wave-uniform)
+    // The wave reserves ray indices a block at a time ([cur, end), scalars) and hands them to its idle lanes from there: the global
+    // cursor's atomic -- a round trip of microseconds that the whole wave waits for -- is paid once per kTicketBlock rays, not at
+    // every refill (which made early refills, i.e. fuller waves, cost more than they brought).
+    uint32_t cur_ray = 0, end_ray = 0;
     for (;;) {
-        // ---------------- refill: idle lanes take the next rays (one atomic per group)
+        // ---------------- refill: idle lanes take the next rays
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
-        if (more && (n_idle >= (MODE == kBounceFirst ? kRefillIdleFirst : kRefillIdle))) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&a.ctl->ticket, n_idle);
-            base = __builtin_amdgcn_readfirstlane(base);
-            more = base + n_idle < total;
-            while (base < total && base >= uniform(s_first[smp_cur + 1])) ++smp_cur; // scalar
-            const uint32_t g = base + mbcnt(idle);
-            if (!alive && g < total) {
+        if ((more || cur_ray < end_ray) && (n_idle >= (MODE == kBounceFirst ? kRefillIdleFirst : (PRESHADED ? kRefillIdlePreshaded : kRefillIdle)))) {
+            // idle lane number `rank` takes ray `g`: first what is left of the wave's block, then (one atomic) the head of the next one,
+            // so that every idle lane is served in this pass
+            const uint32_t rank = mbcnt(idle);
+            const uint32_t left = end_ray - cur_ray;
+            uint32_t g = cur_ray + rank;
+            bool take = rank < left;
+            const uint32_t base = left > 0 ? cur_ray : 0xffffffffu; // first ray handed out (for the sample search)
+            cur_ray += umin(n_idle, left);
+            uint32_t first_g = base;
+            if (left < n_idle && more) {
+                uint32_t nb = 0;
+                if (lane == 0) nb = atomicAdd(&a.ctl->ticket, kTicketBlock);
+                nb = __builtin_amdgcn_readfirstlane(nb);
+                const uint32_t b0 = umin(nb, total);
+                end_ray = umin(nb + kTicketBlock, total);
+                more = nb + kTicketBlock < total;
+                const uint32_t want = n_idle - left, got = umin(want, end_ray - b0);
+                if (rank >= left && rank - left < got) {
+                    g = b0 + (rank - left);
+                    take = true;
+                }
+                cur_ray = b0 + got;
+                if (left == 0) first_g = b0;
+            }
+            while (first_g < total && first_g >= uniform(s_first[smp_cur + 1])) ++smp_cur; // scalar
+            if (!alive && take) {
                 smp = smp_cur;
                 while (g >= s_first[smp + 1]) ++smp; // a group rarely straddles samples
                 ray = g - s_first[smp];
@@ -1746,6 +1772,11 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                         const size_t slot = smp * a.batch.queue_stride + ray;
                         a.dense_out[2u * slot + 1u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kDenseInactive));
                     }
+                } else if (PRESHADED) { // the extension ray of hit `ray`, shaded by shade_rays_kernel
+                    const size_t slot = smp * a.batch.queue_stride + ray;
+                    const float4 ra = a.dense_out[2u * slot], rb = a.dense_out[2u * slot + 1u];
+                    ox = ra.x; oy = ra.y; oz = ra.z; pixel_idx = __float_as_uint(ra.w);
+                    dx = rb.x; dy = rb.y; dz = rb.z;
                 } else { // shade (sh:56-156) of hit `ray` of the previous wavefront
                     const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, image, a.scene.shade_rec,
                                         smp * a.batch.queue_stride, smp * a.batch.chunk_stride, a.capacity, a.rng_mode, a.image_width,
@@ -1761,7 +1792,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             }
         }
         if (__ballot(alive) == 0) {
-            if (!more) break;
+            if (!more && cur_ray == end_ray) break;
             continue; // everything fetched so far was outside the image: fetch again
         }
         // ---------------- one round of the four-wide traversal (trace_ray4's loop body) for the lanes that hold a ray
@@ -1812,6 +1843,27 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             alive = false;
         }
     }
+}
+
+// shade (sh:56-156) of every hit of the previous wavefront at full waves, for the refill traversal: one workgroup = one run of
+// kChunk consecutive hits of one sample (blockIdx.y); the extension ray of hit h goes to slot h of the dense array.
+__global__ __launch_bounds__(kExtendThreads) void shade_rays_kernel(RefillArgs a) {
+    const uint32_t smp = blockIdx.y;
+    const uint32_t n = uniform(umin(a.ctl[smp].shade_n, a.capacity));
+    if (blockIdx.x * kChunk >= n) return;
+    wfpt_frame_buffer fb = a.ctl->frame;
+    fb.width = uniform(fb.width); fb.height = uniform(fb.height); fb.frame = uniform(fb.frame) + smp; fb.sample_number = uniform(fb.sample_number);
+    const uint32_t h = blockIdx.x * kChunk + threadIdx.x;
+    if (h >= n) return;
+    const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, a.image + smp * a.batch.image_stride, a.scene.shade_rec,
+                        smp * a.batch.queue_stride, smp * a.batch.chunk_stride, a.capacity, a.rng_mode, a.image_width,
+                        a.scene.prim_kind, a.tile};
+    float ox, oy, oz, dx, dy, dz;
+    uint32_t pixel_idx;
+    shade_hit<true, true>(src, h, n, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
+    const size_t slot = smp * a.batch.queue_stride + h;
+    a.dense_out[2u * slot] = make_float4(ox, oy, oz, __uint_as_float(pixel_idx));
+    a.dense_out[2u * slot + 1u] = make_float4(dx, dy, dz, 0.0f);
 }
 
 // dense per-ray results -> the segment-compacted path-record and miss queues of the fused loop, in ray order
@@ -2102,12 +2154,20 @@ namespace {
 constexpr uint32_t kRefillLdsFixed = 4u * (2u * kMaxBatch + 4u + kStack4Lds * kExtendThreads); // + 64 B per staged node
 }
 
-hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s) {
+hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s, bool preshaded) {
     if (grid == 0) return hipSuccess;
     using Fn = void (*)(RefillArgs);
-    const Fn fn = a.scene.prim_kind == 0 ? (mode == kBounceFirst ? refill_kernel<kBounceFirst, 0> : refill_kernel<kBounceMiddle, 0>)
-                                         : (mode == kBounceFirst ? refill_kernel<kBounceFirst, 1> : refill_kernel<kBounceMiddle, 1>);
+    Fn fn;
+    if (mode == kBounceFirst) fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceFirst, 0> : refill_kernel<kBounceFirst, 1>;
+    else if (preshaded) fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceMiddle, 0, true> : refill_kernel<kBounceMiddle, 1, true>;
+    else fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceMiddle, 0> : refill_kernel<kBounceMiddle, 1>;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kExtendThreads), kRefillLdsFixed + 64u * a.scene.tile_n, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade_rays(const RefillArgs &a, uint32_t n_chunks, hipStream_t s) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(shade_rays_kernel, dim3(n_chunks, a.batch.n), dim3(kExtendThreads), 0, s, a);
     return hipGetLastError();
 }
 
