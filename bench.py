@@ -354,20 +354,20 @@ def main():
         if fused:
             # dominant kernel: the middle bounce launches = shade(b-1) + extend(b) [+ miss_kernel(b-1)], b = 1 .. max-1.
             # Algorithmic bytes = SURVEY 8(d)'s per-unit figures times the units those launches process.
-            kname = ("refill_kernel<middle> (shade + four-wide extend of one wavefront, dynamic lane refill)" if refill else
+            kname = ("refill_kernel<middle> (four-wide extend of one wavefront, dynamic lane refill; its rays come shaded from shade_rays_kernel)" if refill else
                      "bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)")
             kstage = "bounce"
             shaded, applied = wt[:-1, 1].sum(), wt[:-1, 2].sum()        # hits / misses of wavefronts 0 .. max-2
             rays_k, hits_out, miss_out = wt[1:, 0].sum(), wt[1:, 1].sum(), wt[1:, 2].sum()
-            if refill:  # miss_kernel and the compaction are launches of their own there
-                k_bytes = B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out
-                k_own = 56.0 * shaded + 32.0 * rays_k  # record in (32) + throughput RMW (24); one dense 32-byte result per ray out
+            if refill:  # shade, miss_kernel and the compaction are launches of their own there: this launch is extend alone
+                k_bytes = B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out
+                k_own = 64.0 * rays_k  # one 32-byte ray in, one dense 32-byte result out, per ray
             else:
                 k_bytes = (B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied)
                 # what the fused design itself has to move: record in (32), throughput RMW (2 x 16, padded pixels), record out
                 # (32) / miss out (8), applied miss (8 + 32) -- no extension-ray queue, no hit-queue gather
                 k_own = 64.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 40.0 * applied
-            chain_ms = float(sum(ms[W.STAGES[k]] for k in ("bounce_first", "bounce", "bounce_last", "scan", "compact", "miss_kernel")))
+            chain_ms = float(sum(ms[W.STAGES[k]] for k in ("bounce_first", "bounce", "bounce_last", "scan", "compact", "miss_kernel"))) + (shade_ms if refill else 0.0)
         else:
             kname, kstage = "extend_kernel", "extend"
             k_bytes = B_EXTEND_RAY * float(rt[0]) + B_EXTEND_HIT * float(rt[1]) + B_EXTEND_MISS * float(rt[2])
