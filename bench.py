@@ -436,13 +436,14 @@ def main():
         same_shape = bool(pmc) and pmc.get("samples_in_flight") == min(batch, args.spp)
         hbm_per_launch = (pmc or {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"kernel": stage["kname"],
-                           "bound": "valu",
+                           "bound": ("valu" if args.scene == "shirley" and not args.no_lds_scene else "l1"),
                            "bound_note": ("bound by wave64 VALU issue (LDS-resident BVH, no HBM traffic for the scene); achieved / peak / frac are the "
                                           "HBM figures BASELINE asks for, secondary holds the VALU figures (DESIGN.md section 4)"
                                           if args.scene == "shirley" and not args.no_lds_scene else
-                                          "wave64 VALU issue at the ceiling of the four-box visit's instruction mix, with the L1 -> register path of the "
-                                          "per-lane node fetches (TA busy ~0.75) and the L2-miss traffic (`traffic`: a 128-byte line per 64-byte node) "
-                                          "close behind; achieved / peak / frac are the HBM figures BASELINE asks for (DESIGN.md section 8)"),
+                                          "the L1 -> register (TA) path of the per-lane node fetches (busy 0.81 on average, 0.94 on the busiest CU) with wave64 "
+                                          "VALU issue at 90 % of the ceiling of the four-box visit's instruction mix beside it and the L2-miss traffic "
+                                          "(`traffic`: a 128-byte line per 64-byte node) behind; achieved / peak / frac are the HBM figures BASELINE asks "
+                                          "for, of this launch's own (extend) bytes (DESIGN.md section 8)"),
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": round(hbm_per_launch, 1) if (hbm_per_launch and same_shape) else None,

@@ -26,7 +26,7 @@ import sys
 
 NAMES = [("bounce_kernel<0", "bounce_first"), ("bounce_kernel<1", "bounce"), ("bounce_kernel<2", "bounce_last"),
          ("refill_kernel<0", "bounce_first"), ("refill_kernel<1", "bounce"), ("compact_kernel", "compact"),
-         ("extend_kernel", "extend"), ("shade_kernel", "shade"), ("miss_kernel", "miss_kernel"), ("scan_kernel", "scan"),
+         ("extend_kernel", "extend"), ("shade_kernel", "shade"), ("shade_rays_kernel", "shade_rays"), ("miss_kernel", "miss_kernel"), ("scan_kernel", "scan"),
          ("generate_rays_kernel", "generate_rays"), ("accumulate_kernel", "accumulate")]
 
 
