@@ -1,4 +1,4 @@
-"""tools/hunt_conservative.py [width height frames bounces seed leaf_exact] -- CPU only. Runs the oracle's stage chain on the seeded Shirley scene
+"""tests/hunt_conservative.py [width height frames bounces seed leaf_exact] -- CPU only. Runs the oracle's stage chain on the seeded Shirley scene
 and, before every extend, traces the wavefront's rays twice: with the reference's traversal and with the oracle's MODEL of the
 device's conservative traversal (oracle/wfpt_oracle.c: trace_ray_model). Prints every ray whose reported hit differs."""
 import ctypes as C

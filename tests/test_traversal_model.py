@@ -3,7 +3,7 @@ arithmetic (wfpt_kernels.hip: trace_ray_conservative). oracle/wfpt_oracle.c hold
 (trace_ray_model), so its equivalence with the reference's traversal (trace_ray_bvh, extend.wgsl:72-183) is checked here without a
 GPU, on the rays of real wavefronts -- and so is the counter-example that shows why the leaf boxes must stay exact: with EVERY box
 merely conservative a sphere "hit" appears that the reference never tests (the sphere test's discriminant rounds a ray that passes
-~1e-4 outside the sphere into a hit; the reference's ray misses the sphere's box first). tools/hunt_conservative.py runs the same
+~1e-4 outside the sphere into a hit; the reference's ray misses the sphere's box first). tests/hunt_conservative.py runs the same
 comparison over as many frames as one likes (round 3: 9.6e8 rays of seeds 1 and 2 at 1920x1080, no difference)."""
 import ctypes as C
 
@@ -73,7 +73,7 @@ def test_model_of_the_device_walk_equals_the_reference_walk(orc, seed):
 
 
 def test_counter_example_every_box_conservative_is_not_the_reference(orc):
-    """Frame 18 of the 1920x1080 Shirley frame, ray 831426 (found by tools/hunt_conservative.py ... 1 0): the reference hits the
+    """Frame 18 of the 1920x1080 Shirley frame, ray 831426 (found by tests/hunt_conservative.py ... 1 0): the reference hits the
     ground at t = 18.60; brute force over all spheres (the reference's USE_BVH = false branch, extend.wgsl:141-153) and a walk with
     every box grown report sphere 295 at t = 16.49 -- although the ray passes 7.6e-5 OUTSIDE that sphere's box (and the sphere).
     With the leaf boxes exact the model agrees with the reference."""
@@ -108,7 +108,7 @@ def test_counter_example_every_box_conservative_is_not_the_reference(orc):
 
 
 def test_counter_example_visit_order_decides_a_tie(orc):
-    """3840x2160, frame 7, fourth wavefront, ray 974707 (found by tools/hunt_conservative.py 3840 2160 16 4 1 1): the ray
+    """3840x2160, frame 7, fourth wavefront, ray 974707 (found by tests/hunt_conservative.py 3840 2160 16 4 1 1): the ray
     reaches the point where the big glass sphere rests on the ground; both spheres give the bit-equal t = 1.7786857 and the
     reference reports the one its walk meets first. A walk that orders children by conservative distances meets them the other
     way round, so candidates within 2^-18 of each other hand the ray to the reference's own walk (near_tie, wfpt_kernels.hip)."""
