@@ -7,7 +7,7 @@ while-while schedule in wave instructions:
   sort K  : the rays of one 512-ray item are sorted by a key before they are dealt to the 8 waves
   refill  : an item is P rays; a wave whose idle lanes reach T takes new rays from the item's pool between rounds
 
-Usage: python tools/model_schedule.py [width height]
+Usage: python tests/model_schedule.py [width height]
 """
 import ctypes as C
 import os

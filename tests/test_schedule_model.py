@@ -1,4 +1,4 @@
-"""The oracle's diagnostics behind tools/model_schedule.py (design tools, CPU only): they must agree with the chain they model."""
+"""The oracle's diagnostics behind tests/model_schedule.py (design tools, CPU only): they must agree with the chain they model."""
 import ctypes as C
 
 import numpy as np
@@ -50,7 +50,7 @@ def test_schedule_model_runs(orc, monkeypatch, capsys):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("model_schedule", os.path.join(root, "tools", "model_schedule.py"))
+    spec = importlib.util.spec_from_file_location("model_schedule", os.path.join(root, "tests", "model_schedule.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     # wave cost of 64 identical lanes = the lane's own cost: utilisation 1
