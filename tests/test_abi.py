@@ -85,12 +85,13 @@ def test_no_gpu_means_loud_failure(wf):
 
 
 def test_product_never_touches_the_oracle():
-    """oracle/ is test infrastructure: nothing under the package or include/ may mention it."""
+    """oracle/ is test infrastructure: nothing under the package, include/, the examples or tools/ may mention it (only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg do)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for base in ("wavefront_path_tracer_amd", "include"):
+    for base in ("wavefront_path_tracer_amd", "include", "tools", "examples", "wfpt-sys"):
         for dirpath, _, files in os.walk(os.path.join(root, base)):
             for f in files:
-                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".c", ".sh", ".rs")):
                     text = open(os.path.join(dirpath, f)).read()
                     assert "orc_" not in text and "wfpt_oracle" not in text and "from oracle" not in text \
                         and "import oracle" not in text, os.path.join(dirpath, f)
