@@ -19,12 +19,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--all-ranks", action="store_true")
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--spp", type=int, default=64)
+ap.add_argument("--scene", choices=["shirley", "mesh"], default="shirley")
 args = ap.parse_args()
 w, h = 1920, 1080
 
 
 def run(world, rank):
-    pt = W.shirley_path_tracer(w, h, max_wavefronts=8, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=args.spp)
+    make = (lambda *a, **k: W.mesh_path_tracer(a[0], a[1], 1000000, **k)) if args.scene == "mesh" else W.shirley_path_tracer
+    pt = make(w, h, max_wavefronts=8, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=args.spp)
     for _ in range(2):
         pt.reset_progress()
         pt.render(args.spp)
