@@ -1099,6 +1099,7 @@ static int orc_leaf_rejected(const orc_bvh_node *node, const orc_ray *ray, float
     return tmin > tmax || tmax <= 0.0f || tmin > nearest_hit;
 }
 typedef struct { float b[3], no[3], ab[3]; } model_ray;
+static uint64_t model_handovers = 0;
 static int model_enter(const float c3[3], const float h3[3], const model_ray *r, float nearest, float *t_in) {
     float in = -INFINITY, out = INFINITY;
     for (int ax = 0; ax < 3; ax++) {
@@ -1138,9 +1139,9 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
     float nearest = 1e30f;
     orc_hit_payload temp;
     memset(&temp, 0, sizeof temp);
-    uint32_t stack[ORC_MAX_STACK], sp = 0, node = 0;
-    int risk = 0; /* leaf_exact == 2: near-ties, probes and far origins hand the ray to the reference's walk, as the device does */
-    if (leaf_exact == 2) {
+    uint32_t stack[ORC_MAX_STACK], sp = 0, node = 0, best_leaf = 0;
+    int risk = 0; /* leaf_exact >= 2: near-ties, probes and far origins hand the ray to the reference's walk, as the device does */
+    if (leaf_exact >= 2) {
         float fx = ray->origin[0] - extent[3], fy = ray->origin[1] - extent[4], fz = ray->origin[2] - extent[5];
         if ((fx * fx + fy * fy) + fz * fz > extent[6]) { trace_stat st0 = {0, 0, 0}; return trace_ray_bvh(c, ray, hit, &st0); }
     }
@@ -1152,7 +1153,16 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
              * the primitive tests run into a tentative result whatever the box says (with the near-tie watch); the box then
              * decides between keeping it and, if something changed, handing the ray over. */
             int enter = node == 0 || !leaf_exact || !orc_leaf_rejected(nd, ray, nearest);
-            if (leaf_exact == 2) {
+            if (leaf_exact == 3) {
+                /* Mode 3 = the device's walk since round 4 (visit_leaf + leaf_box_verdict): candidates are accepted as they come
+                 * (with the near-tie watch) and ONE box is tested, after the walk: the leaf of the final hit, against the hit's own
+                 * distance. See the argument at leaf_box_verdict in wfpt_kernels.hip. */
+                for (uint32_t i = 0; i < nd->prim_count; i++) {
+                    orc_hit_payload nh;
+                    if (!c->triangles && model_sphere_risk(c, ray, nd->left_first + i, nearest)) risk = 1;
+                    if (hit_prim(c, ray, nd->left_first + i, 0.001f, nearest, &nh)) { nearest = nh.t; temp = nh; best_leaf = node; }
+                }
+            } else if (leaf_exact == 2) {
                 float n2 = nearest;
                 orc_hit_payload t2 = temp;
                 int tie = 0;
@@ -1189,10 +1199,18 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
             node = nd->left_first + (go_right ? 1u : 0u);
         }
     }
-    if (risk) { trace_stat st = {0, 0, 0}; return trace_ray_bvh(c, ray, hit, &st); }
+    if (leaf_exact == 3 && !risk && nearest < 1e30f && best_leaf != 0 && orc_leaf_rejected(&c->nodes[best_leaf], ray, nearest)) risk = 1;
+    if (risk) {
+        trace_stat st = {0, 0, 0};
+#pragma omp atomic
+        model_handovers++;
+        return trace_ray_bvh(c, ray, hit, &st);
+    }
     if (nearest < 1e30f) { *hit = temp; return 1; }
     return 0;
 }
+/* rays the model handed to the reference's walk since the process started (near-tie, failed leaf box of the hit); far origins not counted */
+uint64_t orc_model_handovers(void) { return model_handovers; }
 /* Traces rays 0..n-1 of the ray queue with the reference's traversal and with the model; writes up to max_out records
  * (ray index, kind) of rays whose result differs (leaf_exact = 2: the device's walk; 1: without the near-tie hand-over; 0: also WITHOUT the exact test of leaf boxes, i.e. every
  * box merely conservative -- the variant that is NOT equivalent to the reference, kept to show the counter-example): kind 1 = the model reports a hit the reference does not, 2 = the reference

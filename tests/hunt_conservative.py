@@ -12,7 +12,7 @@ from oracle import oracle as O
 
 w, h, frames, bounces = (int(a) for a in (sys.argv[1:5] + ["1920", "1080", "2", "8"][len(sys.argv) - 1:]))
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-LEAF_EXACT = int(sys.argv[6]) if len(sys.argv) > 6 else 2  # 2: the device's walk; 1: no near-tie hand-over; 0: every box merely conservative (1, 0: NOT equivalent)
+LEAF_EXACT = int(sys.argv[6]) if len(sys.argv) > 6 else 3  # 3: the device's walk (one leaf-box verdict, after the walk); 2: round 3's walk (a verdict per changed leaf); 1: no near-tie hand-over; 0: every box merely conservative (1, 0: NOT equivalent)
 O.build()
 L = O.lib()
 L.orc_model_mismatches.restype = C.c_uint32
@@ -59,4 +59,5 @@ for frame in range(1, frames + 1):
         o.set_counters([0, 0, n, 0])
         if n == 0:
             break
-print("rays compared:", total)
+L.orc_model_handovers.restype = C.c_uint64
+print("rays compared:", total, "handed over by the model (near-tie / leaf box):", int(L.orc_model_handovers()))

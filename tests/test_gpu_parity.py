@@ -238,16 +238,19 @@ def test_tile_sharding_pixel_mode(gpu, orc):
 
 # ------------------------------------------------------------------ BASELINE.json's full size, against golden vectors
 @pytest.mark.parametrize("mode", [0, 1])
-def test_full_hd_against_golden(gpu, mode):
+@pytest.mark.parametrize("config", ["config2", "config4-split-shade", "unfused"])
+def test_full_hd_against_golden(gpu, mode, config):
     """1920x1080, 8 bounces (BASELINE config 2's frame) for 2 samples: per-bounce (rays, hits, misses) tables and
     the SHA-256 of the accumulated image must equal the oracle's committed golden vectors; plus the size-
-    independent properties of the chain."""
+    independent properties of the chain. config4-split-shade: BASELINE config 4 at its stated size -- the per-material shade
+    stages (lambertian / metal / dielectric queues, README.md:19) give the same frame; unfused: the stage kernels one by one."""
     import hashlib
     import os
     W = gpu
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"shirley_1920x1080_mode{mode}.npz"))
     w, h, spp, bounces = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["bounces"])
-    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, rng_mode=mode)
+    flags = {"config2": 0, "config4-split-shade": W.FLAG_SPLIT_SHADE, "unfused": W.FLAG_UNFUSED}[config]
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, rng_mode=mode, flags=flags)
     for s in range(spp):
         pt.render_sample()
         t = pt.bounce_table().astype(np.int64)

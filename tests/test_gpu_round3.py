@@ -58,21 +58,24 @@ def test_exact_traversal_on_an_lds_resident_mesh(gpu, orc, exact):
 
 # ------------------------------------------------------------------ rays aimed at the edges of the argument (builders: helpers.py)
 @pytest.mark.parametrize("scene", ["shirley", "pairs"])
-@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("exact", [False, True, "hbm-binary"])
 def test_adversarial_rays_against_the_oracle(gpu, orc, scene, exact):
+    """exact = "hbm-binary" (ADVICE r3): the scene kept out of LDS and walked as the caller's binary tree, WITHOUT
+    WFPT_FLAG_EXACT_TRAVERSAL -- a context must pick the reference's own walk for it by itself (decide_exact), because the binary
+    walk without the reference's blind descent loses hits on exactly these rays."""
     W = gpu
     w, h = 128, 64
+    walk_flags = (W.FLAG_NO_LDS_SCENE | W.FLAG_BINARY_BVH) if exact == "hbm-binary" else (W.FLAG_EXACT_TRAVERSAL if exact else 0)
     if scene == "shirley":
         inputs = inputs_for(orc, "shirley", w, h)
-        pt = make_tracer(W, "shirley", w, h, flags=W.FLAG_EXACT_TRAVERSAL if exact else 0)
+        pt = make_tracer(W, "shirley", w, h, flags=walk_flags)
     else:
         sp, mt = _close_pairs_scene(orc)
         sp_o, nodes = orc.build_bvh(sp.copy())
         cam, ip, vw = orc.shirley_camera(w, h)
         inputs = (sp_o, mt, nodes, cam, ip, vw)
         cc = W.CameraController(W.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
-        pt = W.PathTracer(W.Scene(sp.view(W.SPHERE).copy(), mt.view(W.MATERIAL)), W.RenderParameters(cc, (w, h)),
-                          flags=W.FLAG_EXACT_TRAVERSAL if exact else 0)
+        pt = W.PathTracer(W.Scene(sp.view(W.SPHERE).copy(), mt.view(W.MATERIAL)), W.RenderParameters(cc, (w, h)), flags=walk_flags)
         assert_bit_equal(pt.bvh_tree.nodes, nodes.view(W.BVH_NODE), "host BVH of the pairs scene")
     o = make_oracle(orc, inputs, w, h)
     n_max = w * h
@@ -93,7 +96,7 @@ def test_adversarial_rays_against_the_oracle(gpu, orc, scene, exact):
     pt.close(); o.close()
 
 
-@pytest.mark.parametrize("where", ["lds", "hbm"])
+@pytest.mark.parametrize("where", ["lds", "hbm", "hbm-binary"])
 @pytest.mark.parametrize("exact", [False, True])
 def test_adversarial_rays_on_a_mesh(gpu, orc, where, exact):
     """The same for triangles (a build extension; the oracle is the only checker): a mesh with exact duplicates (bit-equal
@@ -112,7 +115,8 @@ def test_adversarial_rays_on_a_mesh(gpu, orc, where, exact):
     scene.triangles["e1"] *= np.float32(12.0); scene.triangles["e2"] *= np.float32(12.0)
     _adversarial_mesh(scene.triangles)
     cc = W.CameraController(W.Camera((0.0, 0.0, 30.0), (0.0, 0.0, 0.0)), 40.0, 0.0, 10.0, 0.1, 100.0)
-    flags = (W.FLAG_EXACT_TRAVERSAL if exact else 0) | (W.FLAG_NO_LDS_SCENE if where == "hbm" else 0)
+    flags = (W.FLAG_EXACT_TRAVERSAL if exact else 0) | (W.FLAG_NO_LDS_SCENE if where != "lds" else 0) | \
+            (W.FLAG_BINARY_BVH if where == "hbm-binary" else 0)  # hbm-binary without EXACT: decide_exact picks the reference's walk
     pt = W.PathTracer(scene, W.RenderParameters(cc, (w, h)), mesh_bins=32, flags=flags)
     assert_bit_equal(pt.bvh_tree.nodes, nodes.view(W.BVH_NODE), "host BVH of the adversarial mesh")
     rays = _adversarial_rays_mesh(W, tris_o, nodes, w * h)

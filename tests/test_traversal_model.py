@@ -1,5 +1,6 @@
 """The device's default traversal prunes INNER boxes with a conservative test and tests LEAF boxes with the reference's own
-arithmetic (wfpt_kernels.hip: trace_ray_conservative). oracle/wfpt_oracle.c holds a CPU model of exactly that walk
+arithmetic (wfpt_kernels.hip: trace_ray_conservative; since round 4 ONE leaf box per ray, the final hit's, after the walk:
+leaf_box_verdict, the model's mode 3). oracle/wfpt_oracle.c holds a CPU model of exactly that walk
 (trace_ray_model), so its equivalence with the reference's traversal (trace_ray_bvh, extend.wgsl:72-183) is checked here without a
 GPU, on the rays of real wavefronts -- and so is the counter-example that shows why the leaf boxes must stay exact: with EVERY box
 merely conservative a sphere "hit" appears that the reference never tests (the sphere test's discriminant rounds a ray that passes
@@ -55,8 +56,9 @@ def test_model_of_the_device_walk_equals_the_reference_walk(orc, seed):
         o.set_frame(frame, 0); o.reset_image(); o.set_counters([0, 0, n])
         o.generate_rays(w // 8, h // 8, True)
         for b in range(bounces):
-            cnt, _ = _mismatches(O, o, n, extent, 2)
-            assert cnt == 0, f"seed {seed} frame {frame} bounce {b}: {cnt} rays differ"
+            for mode in (3, 2):  # 3: the device's walk (one leaf-box verdict after the walk, round 4); 2: round 3's (a verdict per changed leaf)
+                cnt, _ = _mismatches(O, o, n, extent, mode)
+                assert cnt == 0, f"seed {seed} frame {frame} bounce {b} mode {mode}: {cnt} rays differ"
             compared += n
             o.extend(*O.workgroup_size_64(max(n, 65)))
             c = o.counters()
@@ -92,6 +94,7 @@ def test_counter_example_every_box_conservative_is_not_the_reference(orc):
     cnt_leaf, _ = _mismatches(O, o, n, extent, 1)
     assert cnt_leaf == 0
     assert _mismatches(O, o, n, extent, 2)[0] == 0
+    assert _mismatches(O, o, n, extent, 3)[0] == 0
     ray = o.rays(n)[831426]
     hit_ref, ref = o.trace_bvh(ray)
     hit_brute, brute = o.trace_brute(ray)
@@ -136,6 +139,7 @@ def test_counter_example_visit_order_decides_a_tie(orc):
     cnt, rows = _mismatches(O, o, n, extent, 1)
     assert cnt >= 1 and 974707 in rows[:, 0]
     assert _mismatches(O, o, n, extent, 2)[0] == 0
+    assert _mismatches(O, o, n, extent, 3)[0] == 0
     o.close()
 
 
@@ -163,5 +167,6 @@ def test_adversarial_rays_model_equals_reference(orc, scene):
     o.set_frame(1, 0); o.write_rays(rays.view(O.RAY)); o.set_counters([0, 0, n])
     extent = _extent(O, inputs[2], inputs[3], inputs[0])
     assert _mismatches(O, o, n, extent, 2)[0] == 0
+    assert _mismatches(O, o, n, extent, 3)[0] == 0
     assert _mismatches(O, o, n, extent, 1)[0] > 20
     o.close()

@@ -113,11 +113,69 @@ def _agree_on_hip_runtime():
     if spec is None or not spec.origin:
         return
     cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # fall back to the system runtime; `import torch` before this package still works as before
+    if not os.path.exists(cand):
+        return
+    # Only a copy that will actually SATISFY libwfpt.so's NEEDED entry may be mapped first: the dynamic loader matches by
+    # DT_SONAME, so a wheel built against another HIP major version (another SONAME) would sit beside the system runtime
+    # that libwfpt.so then pulls in -- two HIP/HSA pairs in one process, the very failure this function exists to avoid.
+    try:
+        want = [n for n in _elf_dynamic(os.environ.get("WFPT_LIB", _build.LIB_PATH))[1] if n.startswith("libamdhip64.so")]
+        soname = _elf_dynamic(cand)[0]
+    except (OSError, ValueError):
+        return
+    if not want or soname != want[0]:
+        return  # a different runtime generation: leave the choice to the load order, as before
+    try:
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # fall back to the system runtime; `import torch` before this package still works as before
+
+
+def _elf_dynamic(path):
+    """(DT_SONAME, [DT_NEEDED ...]) of a 64-bit little-endian ELF shared object, read from the file (nothing is loaded)."""
+    import struct
+    with open(path, "rb") as f:
+        head = f.read(64)
+        if head[:4] != b"\x7fELF" or head[4] != 2 or head[5] != 1:
+            raise ValueError("not a 64-bit little-endian ELF file")
+        shoff, = struct.unpack_from("<Q", head, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", head, 0x3A)
+        f.seek(shoff)
+        sections = [struct.unpack_from("<IIQQQQIIQQ", f.read(shentsize)) for _ in range(shnum)]
+        dyn = next((sec for sec in sections if sec[1] == 6), None)  # SHT_DYNAMIC
+        if dyn is None:
+            raise ValueError("no dynamic section")
+        strtab = sections[dyn[6]]  # sh_link: the string table of the dynamic section
+        f.seek(strtab[4])
+        strings = f.read(strtab[5])
+        f.seek(dyn[4])
+        raw = f.read(dyn[5])
+    soname, needed = None, []
+    for off in range(0, len(raw) - 15, 16):
+        tag, val = struct.unpack_from("<qQ", raw, off)
+        if tag == 0:
+            break
+        if tag in (1, 14):  # DT_NEEDED, DT_SONAME
+            name = strings[val:strings.index(b"\0", val)].decode()
+            if tag == 1:
+                needed.append(name)
+            else:
+                soname = name
+    return soname, needed
+
+
+def _one_hip_runtime_mapped():
+    """After libwfpt.so is loaded: the process must hold exactly one libamdhip64 (see _agree_on_hip_runtime)."""
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    real = {os.path.realpath(x) for x in paths}
+    if len(real) > 1:
+        raise WfptError(-5, "two HIP runtimes are mapped into this process (" + ", ".join(sorted(real)) + "): the GPU can be "
+                            "initialised through one of them only. Import torch before this package, or set LD_LIBRARY_PATH so "
+                            "that libwfpt.so resolves libamdhip64 to the copy PyTorch ships")
 
 
 def _lib_loaded():
@@ -135,6 +193,7 @@ def lib():
                             "(python -m wavefront_path_tracer_amd._build); there is no CPU fallback")
     _agree_on_hip_runtime()
     L = C.CDLL(path)
+    _one_hip_runtime_mapped()
     vp, u32, i32, f32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
     sig = {
         "wfpt_scene_new": (u32, [vp, vp]),
@@ -705,6 +764,7 @@ class PathTracer:
             self._check(lib().wfpt_update_scene(self.handle, _p(scene.spheres), len(scene.spheres), _p(scene.materials),
                                                 len(scene.materials)))
         self.scene = scene
+        self.bvh_tree = None  # the new tree exists on the device only (the primitives above were reordered to match it)
         self.render_progress.reset()
 
     def set_frame(self, frame):

@@ -692,7 +692,11 @@ void camera_reach(const wfpt_gpu_camera &cam, float reach[3]) {
 // boxes' error bound does not cover the rays at hand) or the conservative one.
 void decide_exact(wfpt_ctx *c, const float cam_reach[3]) {
     bool exact = (c->p.flags & WFPT_FLAG_EXACT_TRAVERSAL) != 0 || (c->scene.lds_scene && !c->ch_ok) || c->far_rays;
-    // (scenes beyond LDS without four-wide nodes walk the binary tree with the reference's arithmetic anyway)
+    // A scene beyond LDS without four-wide nodes (WFPT_FLAG_BINARY_BVH, a tree that is not recomputable, a leaf collapse_bvh4
+    // refuses) walks the caller's binary tree: with the reference's own test and its 1e30 miss value, i.e. with its blind descent
+    // (ex:124). trace_ray<EXACT = false> -- the reference's arithmetic but kBoxMiss -- skips that descent and with it hits the
+    // reference reports (tests/test_traversal_model.py); it is never the walk of a context.
+    if (!c->scene.lds_scene && !c->scene.nodes4) exact = true;
     for (int ax = 0; ax < 3 && !exact && c->ch_ok; ++ax)
         if (!(cam_reach[ax] <= 4.0f * c->extent[ax])) exact = true;
     c->scene.exact = exact ? 1u : 0u; // (scenes beyond LDS: the four-wide nodes exist only when the tree passed tree_is_recomputable)
@@ -975,6 +979,13 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     c->classic_batch = c->fused ? 1u : c->batch_max; // the stage API works on slice 0 only
     const size_t nb_all = c->batch_max;
     const size_t nb = c->classic_batch;
+    // The kernels keep slice strides as 32-bit element counts (Stride32: one scalar register each): 7 * capacity floats between
+    // ray-queue slices, 4 * pixel_capacity floats between image slices. Refuse a context whose strides would wrap.
+    if (7ull * cap > 0xffffffffull || 4ull * c->pixel_capacity > 0xffffffffull) {
+        fail(nullptr, WFPT_ERR_UNSUPPORTED, "wfpt_create: ray capacity beyond 2^32 / 7 slots (or 2^30 pixels): slice strides are 32-bit");
+        wfpt_destroy(c);
+        return nullptr;
+    }
 
     for (int k = 0; k < 2; ++k) {
         CREATE_HIP(dmalloc(&c->ray_mem[k], nb * 7 * static_cast<size_t>(c->capacity)));

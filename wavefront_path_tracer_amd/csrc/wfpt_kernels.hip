@@ -424,20 +424,61 @@ __device__ __forceinline__ bool far_origin(const SceneDev &sc, float ox, float o
     return (fx * fx + fy * fy) + fz * fz > sc.safe_r2;
 }
 
-// A leaf of a free walk. The primitive tests run into a TENTATIVE result; if that changed anything, the leaf's own box is grown
-// exactly as the builder computes it and the reference's test of that box (ex:164-183), which is what decides whether these
-// primitives are tested at all (see trace_ray_conservative), gives the verdict:
-//   * Box entered (or never tested: the root, ex:84): the tentative result stands.
-//   * Box failed: the reference does not test these primitives on that account -- but it may test them all the same. While
-//     nothing is hit yet, a pair of boxes the ray misses both of is still entered, left child first (ex:124, `1e30 > 1e30`),
-//     down to the leftmost leaf below, whose primitives are then tested with no box test at all; and a primitive test rounds,
-//     so it can accept a ray that passes a little outside the primitive (e.g. one that lies in the very plane of the box face
-//     it is tangent to). A hit found that way is the reference's hit. So if a primitive here WOULD have been accepted, the ray
-//     is handed to the reference's own walk, which decides; if none would, entering or not makes no difference.
-// (If nothing changed, entering or not makes no difference either, and the box is never computed: the common case.)
+// A leaf of a free walk, and the ONE box test a free walk owes the reference (rewritten in round 4).
+//
+// The reference tests the primitives of exactly those leaves whose own box passes its test (ex:164-183), plus those its blind
+// descent reaches (ex:124, `1e30 > 1e30`); a primitive test rounds, so a free walk -- which reaches every leaf a ray passes within
+// the boxes' margin -- also meets "false positives": primitives the exact test accepts although the ray misses their leaf's box
+// (DESIGN.md section 2). Round 3 asked the leaf's box for a verdict every time a primitive test changed the tentative result,
+// inside the walk's most divergent code. One verdict per ray, after the walk, is enough:
+//   * U = the primitives hit_prim accepts among all the walk tests, T = those the reference tests (T is a subset of U wherever the
+//     walk's own pruning by `nearest` did not cut it short; a pruned box holds nothing nearer than the value that pruned it).
+//     The walk reports b = min U, the reference r = min T (first visited on exactly equal distances).
+//   * If b's leaf passes the reference's box test with entry distance tmin <= t(b), then b is in T: every ancestor's box passes too
+//     (nested boxes, monotone arithmetic) with an entry distance <= tmin <= t(b) <= whatever `nearest` the reference holds when it
+//     gets there (that value is the distance of some member of T, hence >= t(b)), so no `tmin > nearest` prunes the way to b, and a
+//     far child is dropped by `t_far < nearest` only on an exact tie of distances, which the watch below hands over. min U in T
+//     gives b = r.
+//   * Otherwise (the box fails, or the hit computes nearer than its own box's entry distance by rounding, the corner in which the
+//     reference's answer depends on what it found before) the ray is handed to the reference's own walk. An intermediate
+//     false positive that a nearer hit replaced needs no verdict: it can only have pruned what could not beat it.
+//   * Exactly equal distances of two different primitives are the one case left in which the ORDER of visits shows (ex:190-207's
+//     strict `<`): hit_prim<TRACK> watches for candidates within 2^-18 (relative) of the nearest so far and poisons the result.
+// A CPU model of exactly this walk (the checker's "mode 3") is compared with the reference's walk on the rays of real wavefronts:
+// tests/hunt_conservative.py, tests/test_traversal_model.py.
+// `leaf_word` names the leaf for the verdict (LDS-resident scenes: left_first | prim_count << 16; four-wide walk: the child word).
+template <int PRIM>
+__device__ __forceinline__ void visit_leaf(const float4 *geom, uint32_t first, uint32_t count, uint32_t leaf_word, float ox, float oy, float oz,
+                                           float dx, float dy, float dz, float a, float &nearest, uint32_t &best, uint32_t &best_leaf) {
+    const uint32_t before = best;
+    for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM, true>(geom, first + i, ox, oy, oz, dx, dy, dz, a, nearest, best);
+    best_leaf = best != before ? leaf_word : best_leaf;
+}
+// The verdict (see above): the box of leaf [first, first + count), recomputed exactly as the builder computes it, tested with the
+// reference's arithmetic (ex:164-183) against the hit's own distance. box_untested: the root is a leaf (its box is never tested, ex:84).
+template <int PRIM>
+__device__ __forceinline__ void leaf_box_verdict(const float4 *geom, uint32_t first, uint32_t count, bool box_untested, float ox, float oy, float oz,
+                                                 float dx, float dy, float dz, float &nearest, uint32_t &best) {
+    if (best >= kHandOver || box_untested || WFPT_EXP_NO_LEAFBOX) return; // no hit, or handed over already
+    float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // invDirection (gr:87, sh:153)
+    float tmin, tmax;
+    slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
+    if (tmin > tmax || tmax <= 0.0f || tmin > nearest) { // ex:179 with nearest = the hit's own distance
+        if (!WFPT_EXP_NO_TIE) hand_over(nearest, best);
+    }
+}
+
+// The same debt paid inside the walk, as round 3 did everywhere: the primitive tests run into a TENTATIVE result and, if that changed
+// anything, the leaf's own box -- tested against the `nearest` the walk held when it arrived -- decides between keeping it and, if a
+// primitive would have been accepted although the box fails, handing the ray over (the model's mode 2). Kept for refill_kernel: its
+// per-lane state fills the 64 vector registers of 8 waves per SIMD exactly, and the leaf word plus a "result not written yet" flag that
+// the deferred verdict needs pushed its hot loop into scratch (measured: 1.98 -> 1.27 Grays/s on the 1 M-triangle soup with the
+// verdicts batched in front of a refill, 1.86 with one per finished ray; profiles/r04_rejected_experiments.txt).
 // LAZY_INV: the caller does not keep the exact inverse direction (refill_kernel); it is computed where the box is.
 template <int PRIM, bool LAZY_INV = false>
-__device__ __forceinline__ void visit_leaf(const float4 *geom, uint32_t first, uint32_t count, bool box_untested, float ox, float oy, float oz,
+__device__ __forceinline__ void visit_leaf_in_place(const float4 *geom, uint32_t first, uint32_t count, bool box_untested, float ox, float oy, float oz,
                                            float dx, float dy, float dz, float ix, float iy, float iz, float a, float &nearest, uint32_t &best) {
     float n2 = nearest;
     uint32_t b2 = best;
@@ -589,7 +630,7 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 // the reference never sees it, because the ray misses the sphere's BOX and the leaf is never entered. (Found by
 // tools/hunt_conservative.py: with every box grown, 2 rays in 1.6e8 reported such a hit; in the dispatch-keyed RNG mode one
 // changed hit re-keys the rest of the sample.) So boxes are filters the result depends on, and they are treated in two classes:
-//   * LEAF boxes are tested with the reference's own arithmetic (visit_leaf) when the walk arrives at the leaf;
+//   * LEAF boxes are tested with the reference's own arithmetic -- the box of the final hit's leaf, once, after the walk (leaf_box_verdict);
 //   * INNER boxes only have to say "maybe" whenever the reference's test would enter them.
 // That is enough, because the reference's test is MONOTONE in the box: IEEE subtraction and multiplication by a fixed inverse
 // are monotone, so for nested boxes L inside A (a BVH's boxes nest in float coordinates; checked at wfpt_create) every plane
@@ -603,7 +644,7 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 // MORE than this test's own rounding error can reach (build_nodes_ch, wfpt_api.hip): for every ray whose origin lies within
 // four scene extents of the origin, computed entry distance <= the exact box's and computed exit distance >= its exit
 // distance. (wfpt_create falls back to the exact test when a camera or an injected ray lies outside that range, when a box
-// is not finite, or when the caller's leaf boxes are not what visit_leaf recomputes: tree_is_recomputable, wfpt_api.hip.)
+// is not finite, or when the caller's leaf boxes are not what leaf_box_verdict recomputes: tree_is_recomputable, wfpt_api.hip.)
 //   per axis: tc = c * inv - o * inv (one fma against the per-ray constant -(o * inv)),
 //             t_entry = tc - h * |inv|, t_exit = tc + h * |inv| (one fma each; the sign of inv needs no min / max),
 //   entered  <=> max(t_entry over axes, 0) <= min(t_exit over axes, nearest)
@@ -616,9 +657,8 @@ template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
                                                        float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
                                                        uint32_t &prim_out WFPT_DBG_PARAM) {
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz; // dot(direction, direction), ex:190
-    const float bx = min_(max_(ix, -1e30f), 1e30f), by = min_(max_(iy, -1e30f), 1e30f), bz = min_(max_(iz, -1e30f), 1e30f);
+    const float bx = min_(max_(1.0f / dx, -1e30f), 1e30f), by = min_(max_(1.0f / dy, -1e30f), 1e30f), bz = min_(max_(1.0f / dz, -1e30f), 1e30f);
     const float nox = -(ox * bx), noy = -(oy * by), noz = -(oz * bz);
     const float ax = __builtin_fabsf(bx), ay = __builtin_fabsf(by), az = __builtin_fabsf(bz);
     float nearest = 1e30f;
@@ -628,6 +668,8 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
     tr.left_first = __float_as_uint(nodes_ch[0].w);
     tr.prim_count = __float_as_uint(nodes_ch[1].w);
     tr.trail = 0;
+    const bool root_leaf = tr.prim_count != 0u; // the root's own box is never tested (ex:84)
+    uint32_t best_leaf = 0; // the leaf of `best`: left_first | prim_count << 16 (a scene in LDS holds fewer than 2^16 primitives)
     bool alive = true;
     uint32_t budget = max_steps; // see trace_ray
     while (alive) {
@@ -665,10 +707,11 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
 #if WFPT_STAMPS
             dbg[1] = __builtin_amdgcn_readfirstlane(dbg[1]) + 1u;
 #endif
-            visit_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, tr.node == 0u, ox, oy, oz, dx, dy, dz, ix, iy, iz, a, nearest, best);
+            visit_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, tr.left_first | (tr.prim_count << 16), ox, oy, oz, dx, dy, dz, a, nearest, best, best_leaf);
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
+    leaf_box_verdict<PRIM>(prim_geom, best_leaf & 0xffffu, best_leaf >> 16, root_leaf, ox, oy, oz, dx, dy, dz, nearest, best);
     t_out = nearest;
     prim_out = best; // kHandOver: the caller re-traces with the reference's walk
     return nearest < 1e30f; // ex:157
@@ -804,11 +847,10 @@ __device__ __forceinline__ Visit4 visit4_at(const float4 *nodes4, const float4 *
 template <int PRIM>
 __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *prim_geom, Stack4 st, float ox, float oy, float oz, float dx,
                                            float dy, float dz, uint32_t max_steps, bool root_leaf, float &t_out, uint32_t &prim_out) {
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float a = (dx * dx + dy * dy) + dz * dz;
     const Ray4 r4 = make_ray4(ox, oy, oz, dx, dy, dz);
     float nearest = 1e30f;
-    uint32_t best = 0xffffffffu;
+    uint32_t best = 0xffffffffu, best_leaf = 0;
     uint32_t cur = 0; // node 0 is the root's four-wide node (the root's own box is never tested, ex:84)
     bool alive = true;
     uint32_t budget = max_steps; // every node is visited at most once on a valid tree
@@ -830,13 +872,14 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
         }
         if (alive && budget-- == 0) alive = false;
         if (alive) { // leaf child: kLeafFlag | count << 28 | first
-            // the quantised boxes above are LARGER than the caller's: the leaf's own box decides, with the reference's arithmetic
-            // (see trace_ray_conservative), whether its primitives are tested
+            // the quantised boxes above are LARGER than the caller's: the box of the final hit's leaf gets the reference's verdict
+            // after the walk (leaf_box_verdict)
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
-            visit_leaf<PRIM>(prim_geom, first, count, root_leaf, ox, oy, oz, dx, dy, dz, ix, iy, iz, a, nearest, best);
+            visit_leaf<PRIM>(prim_geom, first, count, cur, ox, oy, oz, dx, dy, dz, a, nearest, best, best_leaf);
             if (st.sp == 0) alive = false; else cur = st.pop();
         }
     }
+    leaf_box_verdict<PRIM>(prim_geom, best_leaf & kLeafFirstMask, (best_leaf >> kLeafCountShift) & 7u, root_leaf, ox, oy, oz, dx, dy, dz, nearest, best);
     t_out = nearest;
     prim_out = best;
     return nearest < 1e30f;
@@ -1827,7 +1870,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             } else {
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
                 const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
-                visit_leaf<PRIM, true>(a.scene.prim_geom, first, count, a.scene.root_leaf != 0, r4.ox, r4.oy, r4.oz, dx, dy, dz, 0.f, 0.f, 0.f, aa, nearest, best); // see trace_ray4
+                visit_leaf_in_place<PRIM, true>(a.scene.prim_geom, first, count, a.scene.root_leaf != 0, r4.ox, r4.oy, r4.oz, dx, dy, dz, 0.f, 0.f, 0.f, aa, nearest, best); // see trace_ray4
                 if (st.sp == 0) fin = true; else cur = st.pop();
             }
         }
