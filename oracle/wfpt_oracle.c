@@ -39,12 +39,15 @@ static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z -
 static inline v3 v3_scale(float s, v3 a) { return v3_make(s * a.x, s * a.y, s * a.z); }
 static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 static inline float v3_length(v3 a) { return orc_sqrt(v3_dot(a, a)); }
-/* WGSL normalize(v) = v / length(v): true division per component */
-static inline v3 v3_normalize(v3 a) { float l = v3_length(a); return v3_make(a.x / l, a.y / l, a.z / l); }
+/* WGSL normalize(v): the built-in's accuracy is "inherited from v / length(v)", i.e. 2.5 ULP per component on top of length's;
+ * the definition fixed here (round 4) is v * (1 / length(v)) -- ONE correctly rounded division and a correctly rounded product
+ * per component, at most 1.5 ULP away from v / length(v) (tests/test_oracle_math.py::test_normalize_accuracy), and what a shader
+ * compiler emits for the built-in on most targets. Rounds 1-3 divided each component. */
+static inline v3 v3_normalize(v3 a) { float inv = 1.0f / v3_length(a); return v3_make(a.x * inv, a.y * inv, a.z * inv); }
 static inline float v4_dot(v4 a, v4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 static inline v4 v4_normalize(v4 a) {
-    float l = orc_sqrt(v4_dot(a, a));
-    v4 r = {a.x / l, a.y / l, a.z / l, a.w / l};
+    float inv = 1.0f / orc_sqrt(v4_dot(a, a));
+    v4 r = {a.x * inv, a.y * inv, a.z * inv, a.w * inv};
     return r;
 }
 /* WGSL mat4x4f * vec4f with m stored column-major: sum of columns scaled by the vector's components */
@@ -1208,6 +1211,13 @@ static int trace_ray_model(const orc_ctx *c, const orc_ray *ray, const float ext
     }
     if (nearest < 1e30f) { *hit = temp; return 1; }
     return 0;
+}
+/* test probe: normalize of n 3-vectors (xyz interleaved) */
+void orc_probe_normalize3(const float *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        v3 r = v3_normalize(v3_make(in[3 * i], in[3 * i + 1], in[3 * i + 2]));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
 }
 /* rays the model handed to the reference's walk since the process started (near-tie, failed leaf box of the hit); far origins not counted */
 uint64_t orc_model_handovers(void) { return model_handovers; }

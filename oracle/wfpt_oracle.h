@@ -150,6 +150,8 @@ void     orc_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_sample
 int      orc_num_threads(void);
 
 /* model of the DEVICE's conservative traversal vs the reference's, over the ray queue (see wfpt_oracle.c) */
+void     orc_probe_normalize3(const float *in, float *out, size_t n); /* test probe */
+uint64_t orc_model_handovers(void); /* diagnostics */
 uint32_t orc_model_mismatches(orc_ctx *c, uint32_t n, const float extent[7], int leaf_exact, uint32_t *out, uint32_t max_out);
 
 #ifdef __cplusplus

@@ -49,3 +49,30 @@ def test_pow_accuracy(orc):
     o = np.zeros(4, "<f4")
     L.orc_probe_pow(orc._p(sp), orc._p(ys), orc._p(o), 4)
     assert o[0] == 0.0 and o[1] == 1.0 and np.isnan(o[2]) and o[3] == 0.0
+
+
+def test_normalize_accuracy(orc):
+    """normalize(v) is defined as v * (1 / length(v)) since round 4 (oracle/wfpt_oracle.c: v3_normalize; the device: normalize3).
+    WGSL gives the built-in the accuracy of v / length(v), i.e. the division's 2.5 ULP on top of whatever length() returned. So
+    each component must lie within 2.5 ULP of the exact quotient by the SAME fp32 length (it lies within 1.5: a correctly rounded
+    reciprocal and a correctly rounded product); against the true unit vector the old and the new definition are equally good."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_probe_normalize3.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(11)
+    n = 1_000_000
+    v = (rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 3, size=(n, 1))).astype("<f4")
+    v[:1000] = rng.normal(size=(1000, 3)).astype("<f4") * np.float32(1e-12)  # tiny vectors: the squares stay normal down to ~1e-19
+    out = np.zeros_like(v)
+    L.orc_probe_normalize3(orc._p(v), orc._p(out), n)
+    length32 = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])  # fp32, the definition's operation order
+    assert length32.dtype == np.float32
+    v64 = v.astype(np.float64)
+    quotient = v64 / length32.astype(np.float64)[:, None]
+    sel = np.abs(quotient) > 1e-30
+    err = ulp_err(out[sel], quotient[sel]).max()
+    assert err <= 1.5, err
+    true_unit = v64 / np.linalg.norm(v64, axis=1, keepdims=True)
+    per_component = (v64 / length32.astype(np.float64)[:, None]).astype(np.float32)  # rounds 1-3: a division per component
+    assert ulp_err(out[sel], true_unit[sel]).max() < ulp_err(per_component[sel], true_unit[sel]).max() + 0.5
+    assert np.abs(np.linalg.norm(out.astype(np.float64), axis=1) - 1.0).max() < 3e-7

@@ -751,11 +751,11 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
             const wfpt_material &m = materials[spheres ? spheres[i].material_idx : triangles[i].material_idx];
             if (spheres) {
                 r.v[0] = spheres[i].center[0]; r.v[1] = spheres[i].center[1]; r.v[2] = spheres[i].center[2];
-            } else { // normalize(cross(e1, e2)): fixed operation order, true divisions, no contraction (-ffp-contract=off)
+            } else { // normalize(cross(e1, e2)): fixed operation order, v * (1 / length) like the kernels' normalize3, no contraction (-ffp-contract=off)
                 const float *e1 = triangles[i].e1, *e2 = triangles[i].e2;
                 const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-                const float len = std::sqrt((nx * nx + ny * ny) + nz * nz);
-                r.v[0] = nx / len; r.v[1] = ny / len; r.v[2] = nz / len;
+                const float inv_len = 1.0f / std::sqrt((nx * nx + ny * ny) + nz * nz);
+                r.v[0] = nx * inv_len; r.v[1] = ny * inv_len; r.v[2] = nz * inv_len;
             }
             r.fuzz = m.fuzz;
             r.albedo[0] = m.albedo[0]; r.albedo[1] = m.albedo[1]; r.albedo[2] = m.albedo[2];

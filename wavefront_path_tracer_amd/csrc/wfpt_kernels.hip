@@ -121,9 +121,9 @@ __device__ __forceinline__ PrimaryRay primary_ray(const CameraDev &cam, uint32_t
         pp = {tf * pp.x - p_lens.x, tf * pp.y - p_lens.y, tf * pp.z - p_lens.z, tf * pp.w - p_lens.w};
     }
     const float4_ rd = mat_mul(cam.view, {pp.x, pp.y, pp.z, 0.0f}); // gr:84
-    // normalize(vec4) (gr:86): length = sqrt(((x*x + y*y) + z*z) + w*w)
-    const float len = sqrt_(((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z) + rd.w * rd.w);
-    return {origin.x, origin.y, origin.z, rd.x / len, rd.y / len, rd.z / len};
+    // normalize(vec4) (gr:86): v * (1 / length), length = sqrt(((x*x + y*y) + z*z) + w*w) (wfpt_device_math.h: normalize3)
+    const float inv_len = 1.0f / sqrt_(((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z) + rd.w * rd.w);
+    return {origin.x, origin.y, origin.z, rd.x * inv_len, rd.y * inv_len, rd.z * inv_len};
 }
 
 // ================================================================================================
