@@ -104,6 +104,12 @@ def main():
                 "post-shade: (4) x dir.y sign (8)": np.where(is_ground == 1, 0, mat + 1) * 2 + (dn[:, 1] > 0),
                 "post-shade: ground|other x dir.y 8 bins (16)": is_ground * 8 + np.clip(((dn[:, 1] + 1.0) * 4).astype(np.int64), 0, 7),
                 "post-shade: (4) x dir.y 4 bins (16)": np.where(is_ground == 1, 0, mat + 1) * 4 + np.clip(((dn[:, 1] + 1.0) * 2).astype(np.int64), 0, 3),
+                "(4), metal x exact dir.y>0 (5)": np.where(is_ground == 1, 0, np.where(mat == 1, 4 + (dn[:, 1] > 0), mat + 1)),
+                "(4), metal+diel x exact dir.y 4 bins": np.where(is_ground == 1, 0, np.where(mat >= 1, 4 + (mat - 1) * 4 + np.clip(((dn[:, 1] + 1.0) * 2).astype(np.int64), 0, 3), 1)),
+                "post-shade: all x dir.y 8 bins": np.clip(((dn[:, 1] + 1.0) * 4).astype(np.int64), 0, 7),
+                "post-shade: ground|other x dir.y 4 bins (8)": is_ground * 4 + np.clip(((dn[:, 1] + 1.0) * 2).astype(np.int64), 0, 3),
+                "post-shade: ground x dir.y 6 quantiles | other (7)": np.where(is_ground == 1, quantile_bins(dn[:, 1], 6), 6),
+                "post-shade: ground x dir.y 4q | lamb x 2 | metal x 2 | diel (9)": np.where(is_ground == 1, quantile_bins(dn[:, 1], 4), np.where(mat == 2, 8, 4 + 2 * np.minimum(mat, 1) + (dn[:, 1] > 0.3))),
                 "upper bound: true cost, 16 bins": quantile_bins(lane_work(segs, nl), 16),
             }
             tot0 = base["trace"] + base["shade"]

@@ -418,7 +418,9 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
         // HBM-resident scene: traversal with dynamic lane refill. Per wavefront: (miss_kernel of the previous one) |
         // refill-trace into dense per-ray records | compact into the queues | scan; then shade+miss of the last one.
         const uint32_t grid = c->cus * c->bounce_blocks_per_cu;
-        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_refill(refill_args(c, 1, nb), kBounceFirst, grid, c->stream); }));
+        if (WFPT_PRESHADE) // generate_rays at full waves into the dense array, then the traversal refills from it
+            WFPT_HIP(c, timed(WFPT_STAGE_GENERATE_RAYS, [&] { return launch_generate_dense(refill_args(c, 1, nb), c->stream); }));
+        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_refill(refill_args(c, 1, nb), kBounceFirst, grid, c->stream, WFPT_PRESHADE != 0); }));
         for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
             const int par = static_cast<int>(b & 1u);
             WFPT_HIP(c, timed(WFPT_STAGE_COMPACT, [&] { return launch_compact(compact_args(c, par, nb), c->n_chunks_max, c->stream); }));

@@ -259,10 +259,14 @@ constexpr uint32_t kTicketBlock = WFPT_TICKET_BLOCK; // ray indices a wave of th
 #ifndef WFPT_REFILL_IDLE_PRESHADED
 #define WFPT_REFILL_IDLE_PRESHADED 24
 #endif
+#ifndef WFPT_REFILL_IDLE_FIRST_PRE
+#define WFPT_REFILL_IDLE_FIRST_PRE 16 // first wavefront with pre-generated primary rays (generate_dense_kernel)
+#endif
 #ifndef WFPT_PRESHADE
 #define WFPT_PRESHADE 1 // middle wavefronts of the refill traversal: shade in a kernel of its own (shade_rays_kernel), rays through the dense array
 #endif
-constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE, kRefillIdleFirst = WFPT_REFILL_IDLE_FIRST, kRefillIdlePreshaded = WFPT_REFILL_IDLE_PRESHADED;
+constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE, kRefillIdleFirst = WFPT_REFILL_IDLE_FIRST, kRefillIdlePreshaded = WFPT_REFILL_IDLE_PRESHADED,
+                   kRefillIdleFirstPre = WFPT_REFILL_IDLE_FIRST_PRE;
 
 struct RefillArgs {
     Batch batch;
@@ -337,6 +341,7 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s); // one workgroup per s
 hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s);
 hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s, bool preshaded = false);
 hipError_t launch_shade_rays(const RefillArgs &a, uint32_t n_chunks, hipStream_t s);
+hipError_t launch_generate_dense(const RefillArgs &a, hipStream_t s); // the first wavefront's primary rays into the dense array (WFPT_PRESHADE)
 hipError_t launch_compact(const CompactArgs &a, uint32_t n_chunks, hipStream_t s);
 hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks);
 uint32_t bounce_lds_bytes(uint32_t n_nodes, uint32_t n_prims, uint32_t prim_kind, bool lds_scene);

@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         // ---------------- refill: idle lanes take the next rays
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
-        if ((more || cur_ray < end_ray) && (n_idle >= (MODE == kBounceFirst ? kRefillIdleFirst : (PRESHADED ? kRefillIdlePreshaded : kRefillIdle)))) {
+        if ((more || cur_ray < end_ray) && (n_idle >= (PRESHADED ? (MODE == kBounceFirst ? kRefillIdleFirstPre : kRefillIdlePreshaded) : (MODE == kBounceFirst ? kRefillIdleFirst : kRefillIdle)))) {
             // idle lane number `rank` takes ray `g`: first what is left of the wave's block, then (one atomic) the head of the next one,
             // so that every idle lane is served in this pass
             const uint32_t rank = mbcnt(idle);
@@ -1800,7 +1800,13 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 fb.frame += smp;
                 bool ok = true;
                 float ox = 0, oy = 0, oz = 0;
-                if (MODE == kBounceFirst) { // generate_rays (gr:42-91), true-size semantics
+                if (PRESHADED) { // the ray waits in the dense array: the extension ray of hit `ray` (shade_rays_kernel), or primary ray `ray` (generate_dense_kernel)
+                    const size_t slot = smp * a.batch.queue_stride + ray;
+                    const float4 ra = a.dense_out[2u * slot], rb = a.dense_out[2u * slot + 1u];
+                    ox = ra.x; oy = ra.y; oz = ra.z; pixel_idx = __float_as_uint(ra.w);
+                    dx = rb.x; dy = rb.y; dz = rb.z;
+                    if (MODE == kBounceFirst) ok = __float_as_uint(rb.w) != kDenseInactive; // a lane outside the image: neither hit nor miss, the marker stays
+                } else if (MODE == kBounceFirst) { // generate_rays (gr:42-91), true-size semantics
                     const uint32_t workgroup_index = ray >> 6, local_index = ray & 63u;
                     const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
                     const uint32_t id_x = wx * 8u + (local_index & 7u);
@@ -1815,11 +1821,6 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                         const size_t slot = smp * a.batch.queue_stride + ray;
                         a.dense_out[2u * slot + 1u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kDenseInactive));
                     }
-                } else if (PRESHADED) { // the extension ray of hit `ray`, shaded by shade_rays_kernel
-                    const size_t slot = smp * a.batch.queue_stride + ray;
-                    const float4 ra = a.dense_out[2u * slot], rb = a.dense_out[2u * slot + 1u];
-                    ox = ra.x; oy = ra.y; oz = ra.z; pixel_idx = __float_as_uint(ra.w);
-                    dx = rb.x; dy = rb.y; dz = rb.z;
                 } else { // shade (sh:56-156) of hit `ray` of the previous wavefront
                     const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, image, a.scene.shade_rec,
                                         smp * a.batch.queue_stride, smp * a.batch.chunk_stride, a.capacity, a.rng_mode, a.image_width,
@@ -1907,6 +1908,32 @@ __global__ __launch_bounds__(kExtendThreads) void shade_rays_kernel(RefillArgs a
     const size_t slot = smp * a.batch.queue_stride + h;
     a.dense_out[2u * slot] = make_float4(ox, oy, oz, __uint_as_float(pixel_idx));
     a.dense_out[2u * slot + 1u] = make_float4(dx, dy, dz, 0.0f);
+}
+
+// generate_rays (gr:42-91, true-size semantics) of the first wavefront at full waves, for the refill traversal: primary ray g of sample
+// blockIdx.y goes to slot g of the dense array, (o | pixel), (d | 0); a lane outside the image leaves the inactive marker. Generating at
+// refill time ran ~250 instructions for the 16-24 idle lanes of a wave and kept the first launch's kernel 12 vector registers over budget.
+__global__ __launch_bounds__(256) void generate_dense_kernel(RefillArgs a) {
+    const uint32_t smp = blockIdx.y;
+    const uint32_t n = umin(a.gx * a.gy * 64u, a.capacity);
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    wfpt_frame_buffer fb = a.ctl->frame;
+    fb.width = uniform(fb.width); fb.height = uniform(fb.height); fb.frame = uniform(fb.frame) + smp; fb.sample_number = uniform(fb.sample_number);
+    const uint32_t workgroup_index = g >> 6, local_index = g & 63u; // one wave = one 8x8 tile of generate_rays
+    const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
+    const uint32_t id_x = wx * 8u + (local_index & 7u);
+    const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
+    const size_t slot = smp * a.batch.queue_stride + g;
+    if (id_x < fb.width && id_y < fb.height) {
+        const uint32_t pixel_idx = id_x + id_y * fb.width; // gr:57
+        const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
+        a.dense_out[2u * slot] = make_float4(pr.ox, pr.oy, pr.oz, __uint_as_float(pixel_idx));
+        a.dense_out[2u * slot + 1u] = make_float4(pr.dx, pr.dy, pr.dz, 0.0f);
+        *pixel_of(a.image + smp * a.batch.image_stride, local_pixel(pixel_idx, fb.width, a.tile)) = make_float4(1.0f, 1.0f, 1.0f, 1.0f); // pt:305-306 folded in
+    } else {
+        a.dense_out[2u * slot + 1u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kDenseInactive));
+    }
 }
 
 // dense per-ray results -> the segment-compacted path-record and miss queues of the fused loop, in ray order
@@ -2201,7 +2228,8 @@ hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream
     if (grid == 0) return hipSuccess;
     using Fn = void (*)(RefillArgs);
     Fn fn;
-    if (mode == kBounceFirst) fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceFirst, 0> : refill_kernel<kBounceFirst, 1>;
+    if (mode == kBounceFirst && preshaded) fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceFirst, 0, true> : refill_kernel<kBounceFirst, 1, true>;
+    else if (mode == kBounceFirst) fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceFirst, 0> : refill_kernel<kBounceFirst, 1>;
     else if (preshaded) fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceMiddle, 0, true> : refill_kernel<kBounceMiddle, 1, true>;
     else fn = a.scene.prim_kind == 0 ? refill_kernel<kBounceMiddle, 0> : refill_kernel<kBounceMiddle, 1>;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kExtendThreads), kRefillLdsFixed + 64u * a.scene.tile_n, s, a);
@@ -2211,6 +2239,13 @@ hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream
 hipError_t launch_shade_rays(const RefillArgs &a, uint32_t n_chunks, hipStream_t s) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(shade_rays_kernel, dim3(n_chunks, a.batch.n), dim3(kExtendThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_dense(const RefillArgs &a, hipStream_t s) {
+    const uint32_t n = a.gx * a.gy * 64u < a.capacity ? a.gx * a.gy * 64u : a.capacity;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(generate_dense_kernel, dim3((n + 255u) / 256u, a.batch.n), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
