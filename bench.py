@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="CPU-baseline sample: whole samples per pixel of the same frame until this much time is spent")
     ap.add_argument("--no-stage-times", action="store_true")
+    ap.add_argument("--no-pixel-anchor", action="store_true",
+                    help="N = 1, --rng-mode auto: skip the pixel-keyed repeat of the timed frames (`value_pixel_mode`, the anchor of scaling sweeps)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = the frame is gathered by RCCL over xGMI through the C ABI (one GPU per rank). gloo: rehearsal "
                          "only -- ranks may share one GPU, the gather goes through host memory")
@@ -116,9 +118,11 @@ def cpu_baseline(args, rng_mode):
             break
     rays = int(o.totals()[0])
     cores = O.lib().orc_num_threads()
+    host_cores, owned = os.cpu_count() or cores, len(os.sched_getaffinity(0))
     out = {"value": round(rays / el / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "host_cores": host_cores,
            "sample": f"the first {spp} of the frame's {args.spp} samples per pixel ({args.width}x{args.height}, {args.bounces} bounces, "
-                     f"{rays} rays, {el:.1f} s, OpenMP x{cores})"}
+                     f"{rays} rays, {el:.1f} s, OpenMP x{cores}: {cores} of the box's {host_cores} cores, {owned} in this job's affinity mask)"}
     image = o.accumulated().copy()
     o.close()
     # single-thread figure: the serial twin of the oracle on one sample per pixel of the same frame
@@ -142,6 +146,23 @@ def baseline_metric():
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
         return "Mrays/s (extend+shade) at 1920×1080, 64 spp, 8 bounces; 1/2/4/8 GPU"
+
+
+def provenance(W, gpu_index):
+    """Where this line comes from: the command, the commit the library was built from (stamped at build time: the GPU box has no
+    .git), whether the sources still match that build, the device and the date."""
+    import datetime
+    from wavefront_path_tracer_amd import _build
+    info = _build.build_info()
+    try:
+        import torch
+        dev = {"name": torch.cuda.get_device_name(gpu_index)}
+    except Exception:
+        dev = {"name": None}
+    return {"command": "python " + " ".join([os.path.basename(sys.argv[0])] + sys.argv[1:]),
+            "git_head": info.get("git_head"), "git_dirty_at_build": info.get("git_dirty"), "library_built_utc": info.get("built_utc"),
+            "source_sha256": info.get("source_sha256"), "sources_match_build": info.get("sources_match_build"),
+            "device": dev.get("name"), "date_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ")}
 
 
 def load_pmc(scene, variant):
@@ -335,6 +356,30 @@ def main():
         if not np.array_equal(np.ascontiguousarray(frame).view(np.uint32), np.ascontiguousarray(pt.accumulated()).view(np.uint32)):
             fail("RCCL branch: the gathered frame differs from the accumulated image")
 
+    # ---- the anchor of a scaling sweep. N > 1 runs are pixel-keyed (band sharding must not change the image), N = 1 runs
+    # dispatch-keyed (reference-faithful) by default, and the pixel-keyed chain traces ~6 % more rays per frame: a 1 -> N ratio
+    # should compare like with like, so the N = 1 line also carries the pixel-keyed figure of the same K frames.
+    pixel_anchor = None
+    if world == 1 and mode_name == "dispatch" and args.rng_mode == "auto" and not args.no_pixel_anchor:
+        kw2 = dict(kw, rng_mode=W.RNG_PIXEL)
+        pt2 = (W.mesh_path_tracer(args.width, args.height, args.triangles, **kw2) if args.scene == "mesh"
+               else W.shirley_path_tracer(args.width, args.height, **kw2))
+        for _ in range(max(min(args.warmup, 2), 1)):
+            pt2.reset_progress(); pt2.render(args.spp)
+        pt2.synchronize()
+        r2 = pt2.totals().copy()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            pt2.reset_progress(); pt2.render(args.spp)
+        pt2.synchronize()
+        e2 = time.perf_counter() - t2
+        pixel_anchor = {"value": round(float((pt2.totals() - r2)[0]) / e2 / 1e6, 3),
+                        "note": ("`value` is dispatch-keyed (shade.wgsl:72's RNG key, the reference's); N > 1 runs are pixel-keyed. `value_pixel_mode` is the "
+                                 f"same {args.steps} frames pixel-keyed on this GPU ({round(e2 / args.steps * 1e3, 4)} ms per frame, "
+                                 f"{int((pt2.totals() - r2)[0])} rays): the N = 1 anchor a 1 -> N scaling ratio should use "
+                                 "(or run every N with --rng-mode pixel)")}
+        pt2.close()
+
     # ---- per-stage times and the roofline of the dominant kernel: the same K frames again with hipEvent pairs around
     # every launch on the context's stream (a second pass, so the events do not perturb `value`)
     stage = None
@@ -351,22 +396,36 @@ def main():
         wt = pt.wavefront_totals().astype(np.float64) - w0  # rows (rays traced, hits, misses) per wavefront over these K frames
         shade_ms = float(sum(ms[W.STAGES[k]] for k in ("shade", "shade_lambertian", "shade_metal", "shade_dielectric")))
         refill = fused and args.scene == "mesh" and not args.no_refill
+        other = None
         if fused:
-            # dominant kernel: the middle bounce launches = shade(b-1) + extend(b) [+ miss_kernel(b-1)], b = 1 .. max-1.
-            # Algorithmic bytes = SURVEY 8(d)'s per-unit figures times the units those launches process.
-            kname = ("refill_kernel<middle> (four-wide extend of one wavefront, dynamic lane refill; its rays come shaded from shade_rays_kernel)" if refill else
-                     "bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)")
-            kstage = "bounce"
+            # Two candidates for "the dominant kernel", both priced with SURVEY 8(d)'s per-unit figures times the units they process:
+            #   middle: the bounce launches of wavefronts 1 .. max-1 = shade(b-1) + extend(b) [+ miss_kernel(b-1)];
+            #   first : the launch of wavefront 0 = generate_rays + extend(0).
+            # The one with the larger share of the frame is `roofline`; the other one is priced beside it (`roofline.other_launch`).
             shaded, applied = wt[:-1, 1].sum(), wt[:-1, 2].sum()        # hits / misses of wavefronts 0 .. max-2
             rays_k, hits_out, miss_out = wt[1:, 0].sum(), wt[1:, 1].sum(), wt[1:, 2].sum()
-            if refill:  # shade, miss_kernel and the compaction are launches of their own there: this launch is extend alone
-                k_bytes = B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out
-                k_own = 64.0 * rays_k  # one 32-byte ray in, one dense 32-byte result out, per ray
+            rays_0, hits_0, miss_0 = wt[0, 0], wt[0, 1], wt[0, 2]
+            pixels = float(args.width) * args.height * args.spp * args.steps / world
+            if refill:  # shade, miss_kernel, generate_rays and the compaction are launches of their own there: these launches are extend alone
+                mid = ("refill_kernel<middle> (four-wide extend of one wavefront, dynamic lane refill; its rays come shaded from shade_rays_kernel)",
+                       B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out,
+                       64.0 * rays_k)  # one 32-byte ray in, one dense 32-byte result out, per ray
+                first = ("refill_kernel<first> (four-wide extend of wavefront 0, dynamic lane refill; its primary rays come from generate_dense_kernel)",
+                         B_EXTEND_RAY * rays_0 + B_EXTEND_HIT * hits_0 + B_EXTEND_MISS * miss_0, 64.0 * rays_0)
             else:
-                k_bytes = (B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied)
-                # what the fused design itself has to move: record in (32), throughput RMW (2 x 16, padded pixels), record out
-                # (32) / miss out (8), applied miss (8 + 32) -- no extension-ray queue, no hit-queue gather
-                k_own = 64.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 40.0 * applied
+                mid = ("bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)",
+                       B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied,
+                       # what the fused design itself has to move: record in (32), throughput RMW (2 x 16, padded pixels), record out
+                       # (32) / miss out (8), applied miss (8 + 32) -- no extension-ray queue, no hit-queue gather
+                       64.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 40.0 * applied)
+                first = ("bounce_kernel<first> (generate_rays + extend of wavefront 0)",
+                         B_GENERATE_PIXEL * pixels + B_EXTEND_RAY * rays_0 + B_EXTEND_HIT * hits_0 + B_EXTEND_MISS * miss_0,
+                         16.0 * pixels + 32.0 * hits_0 + 8.0 * miss_0)  # image reset (16, padded pixel), record / miss out: the ray never leaves registers
+            first_dominant = ms[W.STAGES["bounce_first"]] > ms[W.STAGES["bounce"]]
+            (kname, k_bytes, k_own), kstage = (first, "bounce_first") if first_dominant else (mid, "bounce")
+            o_name, o_bytes, o_own = mid if first_dominant else first
+            o_stage = "bounce" if first_dominant else "bounce_first"
+            other = {"kernel": o_name, "ms": float(ms[W.STAGES[o_stage]]), "n": int(launches[W.STAGES[o_stage]]), "bytes": float(o_bytes), "own": float(o_own)}
             chain_ms = float(sum(ms[W.STAGES[k]] for k in ("bounce_first", "bounce", "bounce_last", "scan", "compact", "miss_kernel"))) + (shade_ms if refill else 0.0)
         else:
             kname, kstage = "extend_kernel", "extend"
@@ -376,7 +435,8 @@ def main():
         stage = {"ms": {k: round(float(ms[v]), 4) for k, v in W.STAGES.items() if launches[v]},
                  "launches": {k: int(launches[v]) for k, v in W.STAGES.items() if launches[v]},
                  "kname": kname, "k_ms": float(ms[W.STAGES[kstage]]), "k_n": int(launches[W.STAGES[kstage]]),
-                 "k_bytes": float(k_bytes), "k_own": float(k_own), "rays": int(rt[0]),
+                 "k_bytes": float(k_bytes), "k_own": float(k_own), "rays": int(rt[0]), "kstage": kstage if fused else "extend", "other": other,
+                 "wavefront_rays": [int(x) for x in wt[:, 0] if x > 0],  # rays traced per wavefront, summed over these K frames
                  "extend_shade_mrays_s": float(rt[0]) / (chain_ms * 1e-3) / 1e6 if chain_ms > 0 else 0.0}
 
     if rank != 0:
@@ -412,8 +472,16 @@ def main():
                    f"pixel bands of 8 rows over {world} ranks + 1 gather per frame ({gather_path})",
                    "gather": gather_path,
                    "gather_check": gather_check,
+                   "gather_verified": ("in this run (gather_check): every N > 1 run checks its own gather; before the first multi-GPU run the ncclSend / ncclRecv "
+                                       "legs had never executed on hardware (one-GPU development boxes)" if (world > 1 and use_rccl) else
+                                       "n/a here; the ncclSend / ncclRecv legs of the N > 1 gather have never run on hardware (one-GPU development boxes): "
+                                       "the first multi-GPU run verifies them itself (gather_check)"),
                    "rays_traced": int(rays_total[0])},
     }
+    out["provenance"] = provenance(W, gpu_index)
+    if pixel_anchor is not None:
+        out["value_pixel_mode"] = pixel_anchor["value"]
+        out["config"]["rng_mode_anchor"] = pixel_anchor["note"]
     info = W.device_info(gpu_index)
     # double data rate: 2 transfers per memory clock; what hipDeviceProp_t reports for this board, next to the spec figure
     peak_device = 2.0 * info["memory_clock_khz"] * 1e3 * info["memory_bus_width_bits"] / 8.0 / 1e9
@@ -434,30 +502,53 @@ def main():
         # PMC counters cannot be collected inside a plain run: `traffic` and `secondary` come from the committed rocprofv3
         # profile of THIS command (same scene, loop variant and samples in flight) and are labelled as such
         same_shape = bool(pmc) and pmc.get("samples_in_flight") == min(batch, args.spp)
-        hbm_per_launch = (pmc or {}).get("hbm_bytes_per_launch")
+        per_kernel = ((pmc or {}).get("launches") or {}) if same_shape else {}
+        pk = per_kernel.get(stage["kstage"], {})
+        fabric = pk.get("fabric_bytes_per_launch")
+        lds_scene = args.scene == "shirley" and not args.no_lds_scene
         out["roofline"] = {"kernel": stage["kname"],
-                           "bound": ("valu" if args.scene == "shirley" and not args.no_lds_scene else "l1"),
+                           "bound": ("valu" if lds_scene else "l1"),
                            "bound_note": ("bound by wave64 VALU issue (LDS-resident BVH, no HBM traffic for the scene); achieved / peak / frac are the "
                                           "HBM figures BASELINE asks for, secondary holds the VALU figures (DESIGN.md section 4)"
-                                          if args.scene == "shirley" and not args.no_lds_scene else
-                                          "the L1 -> register (TA) path of the per-lane node fetches (busy 0.81 on average, 0.94 on the busiest CU) with wave64 "
-                                          "VALU issue at 90 % of the ceiling of the four-box visit's instruction mix beside it and the L2-miss traffic "
-                                          "(`traffic`: a 128-byte line per 64-byte node) behind; achieved / peak / frac are the HBM figures BASELINE asks "
-                                          "for, of this launch's own (extend) bytes (DESIGN.md section 8)"),
+                                          if lds_scene else
+                                          "the L1 -> register (TA) path of the per-lane node fetches with wave64 VALU issue near the ceiling of the four-box "
+                                          "visit's instruction mix beside it and the L2-miss (fabric) traffic behind (`secondary`, `traffic`); achieved / "
+                                          "peak / frac are the HBM figures BASELINE asks for, of this launch's own (extend) bytes (DESIGN.md section 8)"),
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": round(hbm_per_launch, 1) if (hbm_per_launch and same_shape) else None,
-                           "traffic_source": (f"from_profile: {pmc['source']} ({pmc.get('samples_in_flight')} samples in flight, rocprofv3 --pmc of this command)"
-                                              if (hbm_per_launch and same_shape) else None),
+                           "traffic": round(fabric, 1) if fabric else None,
+                           "traffic_source": (f"from_profile: {pmc['source']} ({pmc.get('samples_in_flight')} samples in flight, rocprofv3 --pmc of this command, "
+                                              f"commit {pmc.get('git_head')})" if fabric else None),
+                           "traffic_note": ("FETCH_SIZE x the factor calibrated for this kernel's access shape + WRITE_SIZE: requests on the fabric side of L2 "
+                                            "(MI355X_MICROARCH.md: Infinity-Cache hits are counted, so this is fabric traffic, an upper bound on HBM traffic); "
+                                            + (pk.get("calibration_note") or "")) if fabric else None,
+                           "traffic_per_algorithmic_byte": round(fabric / per_launch_bytes, 3) if fabric and per_launch_bytes else None,
                            "peak_device": round(peak_device, 1),
                            "peak_device_source": f"hipDeviceProp_t: 2 x {info['memory_clock_khz']} kHz x {info['memory_bus_width_bits']} bit / 8",
                            "algorithmic_bytes_per_launch": round(per_launch_bytes, 1),
                            "fused_design_bytes_per_launch": round(stage["k_own"] / max(stage["k_n"], 1), 1),
                            "avg_launch_us": round(avg_s * 1e6, 3), "launches": stage["k_n"]}
-        if pmc and "secondary" in pmc and same_shape:
-            sec = dict(pmc["secondary"])
+        if args.scene == "mesh":  # the scene itself is the compulsory read of an HBM-resident scene: nodes + triangles
+            scene_bytes = 32.0 * 2.0 * args.triangles + 48.0 * args.triangles  # ~2n reference nodes of 32 B + n triangles of 48 B (112 MB at 1 M)
+            out["roofline"]["compulsory_scene_bytes"] = round(scene_bytes, 1)
+            if fabric:
+                out["roofline"]["traffic_per_compulsory_scene_byte"] = round(fabric / scene_bytes, 2)
+        if stage["other"]:
+            o = stage["other"]
+            o_avg = o["ms"] * 1e-3 / max(o["n"], 1)
+            o_bytes = o["bytes"] / max(o["n"], 1)
+            ok = per_kernel.get("bounce_first" if stage["kstage"] == "bounce" else "bounce", {})
+            out["roofline"]["other_launch"] = {"kernel": o["kernel"], "launches": o["n"], "avg_launch_us": round(o_avg * 1e6, 3),
+                                               "algorithmic_bytes_per_launch": round(o_bytes, 1),
+                                               "achieved": round(o_bytes / o_avg / 1e9, 2) if o_avg > 0 else 0.0,
+                                               "frac": round(o_bytes / o_avg / 1e9 / HBM_PEAK_GBS, 5) if o_avg > 0 else 0.0,
+                                               "traffic": round(ok["fabric_bytes_per_launch"], 1) if ok.get("fabric_bytes_per_launch") else None,
+                                               "secondary": ok.get("secondary")}
+        if pk.get("secondary"):
+            sec = dict(pk["secondary"])
             sec["source"] = f"from_profile: {pmc['source']} ({pmc.get('samples_in_flight')} samples in flight)"
             out["roofline"]["secondary"] = sec
+        out["wavefront_rays"] = stage["wavefront_rays"]
         out["stage_ms"] = stage["ms"]
         out["stage_launches"] = stage["launches"]
         out["extend_shade_mrays_s"] = round(stage["extend_shade_mrays_s"], 3)

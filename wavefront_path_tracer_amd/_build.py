@@ -34,6 +34,54 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+BUILD_INFO = os.path.join(PKG_DIR, "build_info.json")
+
+
+def source_digest():
+    """sha256 over the sources libwfpt.so is built from (what a measurement was taken on, wherever git is not at hand)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def write_build_info():
+    """Provenance for bench lines and profiles: the GPU box gets a snapshot without .git, so the commit (and whether the tree was
+    dirty) is stamped here, next to the library, when it is built. Git-ignored like the library; travels with it."""
+    import datetime
+    import json
+
+    def git(*a):
+        try:
+            return subprocess.run(["git", "-C", ROOT] + list(a), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout.strip()
+        except Exception:
+            return ""
+    info = {"git_head": git("rev-parse", "HEAD") or None, "git_dirty": bool(git("status", "--porcelain", "--untracked-files=no")),
+            "built_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"), "source_sha256": source_digest(),
+            "flags": FLAGS + os.environ.get("WFPT_EXTRA_FLAGS", "").split()}
+    try:
+        json.dump(info, open(BUILD_INFO, "w"), indent=1)
+    except OSError:
+        pass
+    return info
+
+
+def build_info():
+    """What write_build_info() left beside the library, checked against the sources as they are now."""
+    import json
+    try:
+        info = json.load(open(BUILD_INFO))
+    except Exception:
+        info = {"git_head": None}
+    try:
+        info["sources_match_build"] = info.get("source_sha256") == source_digest()
+    except OSError:
+        info["sources_match_build"] = None
+    return info
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source into wavefront_path_tracer_amd/libwfpt.so; returns the path."""
     if not force and not stale():
@@ -49,6 +97,8 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + res.stdout)
     if verbose and res.stdout.strip():
         print(res.stdout)
+    if out == LIB_PATH:
+        write_build_info()
     return out
 
 
