@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--split-shade", action="store_true", help="BASELINE config 4: per-material shade stages")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-lds-scene", action="store_true", help="experiment: traverse the scene from HBM / L2 although it fits LDS")
+    ap.add_argument("--no-binning", action="store_true",
+                    help="WFPT_FLAG_NO_BINNING (pixel-keyed RNG): the hit queue stays in thread order (a work item = 512 consecutive hits) instead of being binned by cost class")
+    ap.add_argument("--binning", action="store_true",
+                    help="WFPT_FLAG_BINNING: the class-binned loop in the dispatch-keyed RNG mode too (thread indices carried; same image, slower there)")
     ap.add_argument("--no-refill", action="store_true", help="mesh scene: fused bounce kernel (lanes keep their ray) instead of dynamic lane refill")
     ap.add_argument("--binary-bvh", action="store_true", help="mesh scene: walk the binary tree instead of the four-wide collapse")
     ap.add_argument("--unfused", action="store_true", help="run the stage kernels one by one (extend, scan, shade, miss_kernel per wavefront)")
@@ -216,7 +220,7 @@ def main():
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
              (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0) |
              (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0) |
-             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0))
+             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0) | (W.FLAG_NO_BINNING if args.no_binning else 0) | (W.FLAG_BINNING if args.binning else 0))
     # samples in flight per launch = the whole frame's samples (64): the late wavefronts are small, and a launch of few work
     # items per workgroup ends on a long tail (32 / 64 / 128 in flight: 18.8 / 19.4 / 19.6 Grays/s on a 128-spp job)
     fused = not (args.split_shade or args.unfused)
@@ -461,7 +465,10 @@ def main():
                    "step": (f"one frame: accumulation reset, {args.spp} samples per pixel (each generate_rays -> {args.bounces} x (extend, scan, "
                             "shade, miss_kernel) -> accumulate)" + (", one gather of the frame to rank 0" if world > 1 else "")),
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
-                   "loop": "fused bounce launches" if fused else "stage kernels one by one",
+                   "loop": ("fused bounce launches" + (", hit queue binned by cost class (work item = 512 hits of one class)"
+                                                         if (args.scene == "shirley" and not args.no_lds_scene and
+                                                             (args.binning if mode_name == "dispatch" else not args.no_binning)) else ""))
+                           if fused else "stage kernels one by one",
                    "traversal": (("LDS-resident binary BVH" + (", reference slab arithmetic (exact-traversal)" if args.exact_traversal else ""))
                                  if args.scene == "shirley" and not args.no_lds_scene else
                                  ("binary BVH from HBM" if (args.binary_bvh or args.scene == "shirley") else
@@ -498,6 +505,9 @@ def main():
             variant += "_nolds"
         if args.exact_traversal:
             variant += "_exact"
+        binned = fused and args.scene == "shirley" and not args.no_lds_scene and (args.binning if mode_name == "dispatch" else not args.no_binning)
+        if binned:
+            variant += "_binned"
         pmc = load_pmc(args.scene, variant)
         # PMC counters cannot be collected inside a plain run: `traffic` and `secondary` come from the committed rocprofv3
         # profile of THIS command (same scene, loop variant and samples in flight) and are labelled as such

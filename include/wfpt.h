@@ -186,13 +186,22 @@ enum {
                                         done (the fused bounce kernel) instead of taking new rays as they finish */
     WFPT_FLAG_NO_LDS_SCENE = 1u << 5, /* treat the scene as too large for LDS even if it fits (experiments, tests of the
                                         HBM-resident traversal on small scenes) */
-    WFPT_FLAG_EXACT_TRAVERSAL = 1u << 6 /* trace_ray / hit_bvh_node exactly as extend.wgsl:72-183 writes them: slab planes
+    WFPT_FLAG_EXACT_TRAVERSAL = 1u << 6, /* trace_ray / hit_bvh_node exactly as extend.wgsl:72-183 writes them: slab planes
                                         (b - o) * inv with min / max per axis, a missed box reports 1e30 (so the reference's
                                         `1e30 > 1e30` descent into doubly-missed pairs happens), the binary tree walked as it
                                         is. Default (flag clear): the same walk with a CONSERVATIVE box test (boxes grown by
                                         more than the test's rounding error) -- same hits, fewer instructions; the library
                                         falls back to the exact test by itself when a camera or an injected ray lies outside
                                         the range that bound covers. Same images bit for bit; for bisecting and proofs. */
+    WFPT_FLAG_NO_BINNING = 1u << 7,  /* WFPT_RNG_PIXEL, scenes in LDS: keep the hit queue in thread order (a work item of the fused
+                                        loop = 512 consecutive hits) instead of storing every segment's hits sorted by cost class
+                                        (the dominant primitive | material) and shading / tracing 512 hits of ONE class per work
+                                        item, which is the default there (+2.3 % measured). Same images bit for bit. */
+    WFPT_FLAG_BINNING = 1u << 8      /* run the class-binned loop in WFPT_RNG_DISPATCH too. The reference's order survives -- every
+                                        ray carries its thread index, extend leaves a hit flag per thread index, the scan turns
+                                        the flags into a rank table and shade's thread index (shade.wgsl:72) is recovered from it
+                                        -- so the images are the same bit for bit; but carrying the order costs what the binning
+                                        gains (-5.8 % measured), hence off by default. */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu

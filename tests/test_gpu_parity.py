@@ -102,7 +102,9 @@ CASES = [
 
 @pytest.mark.parametrize("kind,w,h,spp,bounces", CASES)
 @pytest.mark.parametrize("rng_mode", [0, 1])
-@pytest.mark.parametrize("flags", [0, 2, 4, 6])  # fused bounce launches: hipGraph replay / direct; 4 = WFPT_FLAG_UNFUSED: stage kernels one by one
+# fused bounce launches: hipGraph replay / direct; 4 = WFPT_FLAG_UNFUSED: stage kernels one by one; 128 = WFPT_FLAG_NO_BINNING (the pixel-keyed mode's
+# default is the class-binned loop), 256 = WFPT_FLAG_BINNING (the class-binned loop in the dispatch-keyed mode too, thread indices carried)
+@pytest.mark.parametrize("flags", [0, 2, 4, 6, 128, 256, 258])
 def test_device_resident_loop(gpu, orc, kind, w, h, spp, bounces, rng_mode, flags):
     W = gpu
     o = make_oracle(orc, inputs_for(orc, kind, w, h), w, h, rng_mode=rng_mode, max_wavefronts=bounces)
@@ -238,7 +240,7 @@ def test_tile_sharding_pixel_mode(gpu, orc):
 
 # ------------------------------------------------------------------ BASELINE.json's full size, against golden vectors
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("config", ["config2", "config4-split-shade", "unfused"])
+@pytest.mark.parametrize("config", ["config2", "config4-split-shade", "unfused", "binned", "not-binned"])
 def test_full_hd_against_golden(gpu, mode, config):
     """1920x1080, 8 bounces (BASELINE config 2's frame) for 2 samples: per-bounce (rays, hits, misses) tables and
     the SHA-256 of the accumulated image must equal the oracle's committed golden vectors; plus the size-
@@ -249,7 +251,8 @@ def test_full_hd_against_golden(gpu, mode, config):
     W = gpu
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"shirley_1920x1080_mode{mode}.npz"))
     w, h, spp, bounces = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["bounces"])
-    flags = {"config2": 0, "config4-split-shade": W.FLAG_SPLIT_SHADE, "unfused": W.FLAG_UNFUSED}[config]
+    flags = {"config2": 0, "config4-split-shade": W.FLAG_SPLIT_SHADE, "unfused": W.FLAG_UNFUSED,
+             "binned": W.FLAG_BINNING, "not-binned": W.FLAG_NO_BINNING}[config]
     pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, rng_mode=mode, flags=flags)
     for s in range(spp):
         pt.render_sample()
@@ -313,7 +316,7 @@ def test_many_samples_in_flight(gpu, orc):
     spp = 128 + 37
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    for batch, flags in ((128, 0), (100, W.FLAG_NO_GRAPH), (500, 0), (128, W.FLAG_UNFUSED)):
+    for batch, flags in ((128, 0), (100, W.FLAG_NO_GRAPH), (500, 0), (128, W.FLAG_UNFUSED), (128, W.FLAG_BINNING), (100, W.FLAG_BINNING | W.FLAG_NO_GRAPH)):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")
@@ -330,7 +333,7 @@ def test_batched_samples_equal_sequential(gpu, orc, batch):
     w, h, spp, bounces = 200, 120, 19, 5  # 19 = full batches plus a remainder rendered one by one
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED):
+    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED, W.FLAG_BINNING):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")

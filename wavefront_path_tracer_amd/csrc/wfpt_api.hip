@@ -74,6 +74,14 @@ struct wfpt_ctx {
     uint32_t *f_miss_mem[2] = {nullptr, nullptr};
     MissQueue f_mq[2]{};
     uint32_t *f_chunk_hits[2] = {nullptr, nullptr}, *f_chunk_miss[2] = {nullptr, nullptr}, *first_seg = nullptr;
+    // class-binned fused loop (LDS-resident scenes; bounce_binned_kernel): per-segment class totals, the scan's per-class tables, the
+    // work-item plan, and -- dispatch-keyed RNG -- extend's hit flags per thread index with the rank table made of them
+    bool bin_capable = false;     // buffers exist (decided at wfpt_create: fused loop, sizes within the record packing, flag clear)
+    uint32_t *f_cls[2] = {nullptr, nullptr}, *first_seg_cls = nullptr, *plan = nullptr;
+    uint2 *cls_table = nullptr;
+    uint8_t *hit_flags = nullptr;
+    uint4 *rank_table = nullptr;
+    uint32_t bounce_binned_blocks_per_cu = 1;
     // multi-GPU gather of the band-sharded frame (RCCL over xGMI)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -332,6 +340,14 @@ BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb) 
     a.out_miss = c->f_chunk_miss[out_parity];
     a.mq_in = c->f_mq[in_parity];
     a.mq_out = c->f_mq[out_parity];
+    a.plan = c->plan;
+    a.plan_seg_off = nb * kBinClasses + 1u;
+    a.plan_miss_off = a.plan_seg_off + nb + 1u;
+    a.cls_table = c->cls_table;
+    a.first_seg_cls = c->first_seg_cls;
+    a.out_cls = c->f_cls[out_parity];
+    a.rank_in = c->rank_table;
+    a.flag_out = c->hit_flags;
     a.image = c->image;
     a.ctl = c->ctl;
     a.camera = c->camera;
@@ -381,6 +397,40 @@ MissArgs fused_miss_args(wfpt_ctx *c, int parity, uint32_t nb) { // miss_kernel 
     a.mq = c->f_mq[parity];
     a.chunk_miss = c->f_chunk_miss[parity];
     return a;
+}
+ScanBinnedArgs scan_binned_args(wfpt_ctx *c, uint32_t bounce, uint32_t nb, int parity) {
+    ScanBinnedArgs a{};
+    a.batch = batch_of(c, nb);
+    a.chunk_hits = c->f_chunk_hits[parity];
+    a.chunk_miss = c->f_chunk_miss[parity];
+    a.chunk_cls = c->f_cls[parity];
+    a.cls_table = c->cls_table;
+    a.first_seg_cls = c->first_seg_cls;
+    const bool keyed_by_order = c->p.rng_mode != WFPT_RNG_PIXEL;
+    a.flags = keyed_by_order ? c->hit_flags : nullptr;
+    a.rank = keyed_by_order ? c->rank_table : nullptr;
+    a.ctl = c->ctl;
+    a.n_in = &c->ctl->n_in;
+    a.limit = c->capacity;
+    a.miss_floor = c->p.miss_floor;
+    a.bounce = bounce;
+    return a;
+}
+PlanArgs plan_args(wfpt_ctx *c, uint32_t nb, bool last) {
+    PlanArgs a{};
+    a.batch = batch_of(c, nb);
+    a.ctl = c->ctl;
+    a.plan = c->plan;
+    a.plan_seg_off = nb * kBinClasses + 1u;
+    a.plan_miss_off = a.plan_seg_off + nb + 1u;
+    a.last = last ? 1u : 0u;
+    return a;
+}
+// the class-binned loop runs when its buffers exist and the scene at hand is one it is built for: in LDS, primitive indices within
+// the record's 16 bits
+bool use_binned(const wfpt_ctx *c) {
+    return c->bin_capable && c->fused && c->scene.lds_scene && !c->rec_dense && c->scene.n_spheres <= (1u << 16) &&
+           c->batch_max * static_cast<uint32_t>(kBinClasses) <= 512u;
 }
 uint32_t bounce_grid(const wfpt_ctx *c, uint32_t n) {
     // hit items + miss items never exceed 1.25 work items per segment
@@ -434,6 +484,26 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
             } else {
                 WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceLast, bounce_grid(c, nb), c->stream); }));
             }
+        }
+        WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
+                     return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
+                 }));
+        return WFPT_OK;
+    }
+    if (use_binned(c)) {
+        // the same chain with the hit queue binned by cost class: generate+extend | scan, plan | (shade+extend+miss | scan, plan) x (max - 1) | shade+miss | accumulate
+        const uint64_t items = (static_cast<uint64_t>(c->n_chunks_max) * 5u / 4u + 1u) * nb;
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->bounce_binned_blocks_per_cu));
+        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_bounce_binned(bounce_args(c, 1, 0, nb), kBounceFirst, grid, c->stream); }));
+        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+            const int par = static_cast<int>(b & 1u);
+            const bool last = b + 1 >= c->p.max_wavefronts;
+            WFPT_HIP(c, timed(WFPT_STAGE_SCAN, [&] {
+                         hipError_t e = launch_scan_binned(scan_binned_args(c, b, nb, par), c->stream);
+                         return e != hipSuccess ? e : launch_plan(plan_args(c, nb, last), c->stream);
+                     }));
+            WFPT_HIP(c, timed(last ? WFPT_STAGE_BOUNCE_LAST : WFPT_STAGE_BOUNCE,
+                              [&] { return launch_bounce_binned(bounce_args(c, par, par ^ 1, nb), last ? kBounceLast : kBounceMiddle, grid, c->stream); }));
         }
         WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
                      return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
@@ -763,7 +833,30 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
             r.albedo[0] = m.albedo[0]; r.albedo[1] = m.albedo[1]; r.albedo[2] = m.albedo[2];
             r.refract_index = m.refract_index;
             r.mat_type = c->h_prim_mat_type[i]; // sphere.material_type, which extend copies into the payload (ex:199)
-            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            r.cost_class = 1u + std::min<uint32_t>(r.mat_type > 2u ? 0u : r.mat_type, static_cast<uint32_t>(kBinClasses) - 2u); // `case 0u, default` of sh:102
+            r._pad[0] = r._pad[1] = 0;
+        }
+        // cost class 0: the scene's DOMINANT primitives -- those whose own box has at least a quarter of the surface area of the box of
+        // everything (the Shirley scene's ground sphere; none in a triangle soup). Rays that leave such a primitive cost differently from
+        // rays that leave the clutter on it, whatever the material (tests/model_binning.py: the split that buys most of the traversal's gain).
+        {
+            auto area = [](const float lo[3], const float hi[3]) {
+                const double dx = static_cast<double>(hi[0]) - lo[0], dy = static_cast<double>(hi[1]) - lo[1], dz = static_cast<double>(hi[2]) - lo[2];
+                return 2.0 * (dx * dy + dy * dz + dz * dx);
+            };
+            const double root_area = area(nodes[0].aabb_min, nodes[0].aabb_max);
+            for (uint32_t i = 0; i < n_spheres && n_spheres > 1; ++i) {
+                float lo[3], hi[3];
+                for (int ax = 0; ax < 3; ++ax) {
+                    if (spheres) {
+                        lo[ax] = spheres[i].center[ax] - spheres[i].radius; hi[ax] = spheres[i].center[ax] + spheres[i].radius;
+                    } else {
+                        const float v0 = triangles[i].v0[ax], v1 = v0 + triangles[i].e1[ax], v2 = v0 + triangles[i].e2[ax];
+                        lo[ax] = std::fmin(std::fmin(v0, v1), v2); hi[ax] = std::fmax(std::fmax(v0, v1), v2);
+                    }
+                }
+                if (area(lo, hi) >= 0.25 * root_area) recs[i].cost_class = 0u;
+            }
         }
         static_assert(sizeof(ShadeRec) == 48, "ShadeRec is read as three float4");
         WFPT_HIP(c, dmalloc(&c->d_shade_rec, 3 * static_cast<size_t>(n_spheres)));
@@ -835,6 +928,11 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
     int blocks_per_cu = 1;
     WFPT_HIP(c, extend_blocks_per_cu(c->scene, &blocks_per_cu));
     c->blocks_per_cu = static_cast<uint32_t>(std::max(blocks_per_cu, 1));
+    if (c->bin_capable && lds_scene) {
+        int bb = 1;
+        WFPT_HIP(c, bounce_binned_blocks_per_cu(c->scene, &bb));
+        c->bounce_binned_blocks_per_cu = static_cast<uint32_t>(std::max(bb, 1));
+    }
     int bounce_blocks = 1;
     WFPT_HIP(c, bounce_blocks_per_cu(c->scene, &bounce_blocks));
     c->bounce_blocks_per_cu = static_cast<uint32_t>(std::max(bounce_blocks, 1));
@@ -973,10 +1071,23 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     if (c->pixel_capacity > c->n_pixels) cap += 16ull * (static_cast<uint64_t>(c->pixel_capacity) / 8u + 64u) ; // room for partial tiles after a resize
     cap = (cap + kChunk - 1) / kChunk * kChunk;
     if (cap == 0) cap = kChunk;
+    // The class-binned loop cuts every class's hits into work items of kChunk, so a wavefront may fill up to kBinClasses - 1 more
+    // (partly filled) segments than its rays would: room for them. Its records pack a thread index of kBinPixelBits bits beside the
+    // pixel index, so both must stay below 2^23 (3840x2160 does); larger contexts keep the thread-ordered queue.
+    // (default in the pixel-keyed RNG mode, where the order of the queue is free; on request in the dispatch-keyed mode, where carrying the
+    // reference's order through the binning costs what the binning gains: include/wfpt.h, WFPT_FLAG_BINNING)
+    const bool want_binning = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE | WFPT_FLAG_NO_LDS_SCENE)) == 0 &&
+                              (params->rng_mode == WFPT_RNG_PIXEL ? (params->flags & WFPT_FLAG_NO_BINNING) == 0 : (params->flags & WFPT_FLAG_BINNING) != 0);
+    if (want_binning && cap + kBinClasses * kChunk <= (1ull << 23) && c->pixel_capacity <= (1u << 23) &&
+        static_cast<uint64_t>(params->width) * params->height <= (1ull << 23)) {
+        cap += kBinClasses * kChunk;
+        c->bin_capable = true;
+    }
     c->capacity = static_cast<uint32_t>(cap);
     c->n_chunks_max = c->capacity / kChunk;
     // the fused bounce launches keep their per-sample work-item counts as u16 in LDS: larger images stay on the stage kernels
     c->fused = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE)) == 0 && c->n_chunks_max <= 65535u;
+    c->bin_capable = c->bin_capable && c->fused;
     c->batch_max = params->batch == 0 ? 16u : std::min<uint32_t>(params->batch, c->fused ? kMaxBatch : kMaxBatchClassic);
     c->classic_batch = c->fused ? 1u : c->batch_max; // the stage API works on slice 0 only
     const size_t nb_all = c->batch_max;
@@ -1033,6 +1144,23 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         }
         CREATE_HIP(dmalloc(&c->first_seg, counts));
         CREATE_HIP(hipMemsetAsync(c->first_seg, 0, sizeof(uint32_t) * counts, c->stream));
+        if (c->bin_capable) {
+            constexpr size_t kWords = ClsPack<kBinClasses>::kWords;
+            for (int k = 0; k < 2; ++k) {
+                CREATE_HIP(dmalloc(&c->f_cls[k], counts * kWords));
+                CREATE_HIP(hipMemsetAsync(c->f_cls[k], 0, sizeof(uint32_t) * counts * kWords, c->stream));
+            }
+            CREATE_HIP(dmalloc(&c->cls_table, counts * kBinClasses));
+            CREATE_HIP(hipMemsetAsync(c->cls_table, 0, sizeof(uint2) * counts * kBinClasses, c->stream));
+            CREATE_HIP(dmalloc(&c->first_seg_cls, counts * kBinClasses));
+            CREATE_HIP(hipMemsetAsync(c->first_seg_cls, 0, sizeof(uint32_t) * counts * kBinClasses, c->stream));
+            CREATE_HIP(dmalloc(&c->plan, kMaxBatch * (kBinClasses + 2) + 8));
+            CREATE_HIP(hipMemsetAsync(c->plan, 0, sizeof(uint32_t) * (kMaxBatch * (kBinClasses + 2) + 8), c->stream));
+            CREATE_HIP(dmalloc(&c->hit_flags, slots));
+            CREATE_HIP(hipMemsetAsync(c->hit_flags, 0, slots, c->stream));
+            CREATE_HIP(dmalloc(&c->rank_table, slots / 64));
+            CREATE_HIP(hipMemsetAsync(c->rank_table, 0, sizeof(uint4) * (slots / 64), c->stream));
+        }
     }
     CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->acc_floats, c->stream));         // pt:60-65
     CREATE_HIP(dmalloc(&c->ctl, kMaxBatch));
@@ -1161,7 +1289,8 @@ void wfpt_destroy(wfpt_ctx *c) {
     for (auto e : c->sample_events) (void)hipEventDestroy(e);
     free_scene(c);
     void *bufs[] = {c->rec_dense, c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
-                    c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg,
+                    c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg, c->f_cls[0], c->f_cls[1], c->first_seg_cls, c->plan, c->cls_table,
+                    c->hit_flags, c->rank_table,
                     c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera, c->d_stamps};

@@ -28,6 +28,7 @@ constexpr int kScanThreads = 1024;
 constexpr int kMaxRows = 64;       // per-bounce table rows kept on the device
 constexpr int kMaxTrailDepth = 63; // traversal keeps one pending bit per tree level in a u64
 constexpr int kMaxBatch = 128;     // samples kept in flight by one launch of the device-resident loop (fused bounce launches)
+constexpr int kClsMax = 8;         // cost classes of the class-binned fused loop (Control::cls_n)
 constexpr int kMaxBatchClassic = 64; // ... by the stage kernels one by one (WFPT_FLAG_UNFUSED / WFPT_FLAG_SPLIT_SHADE): their LDS tables are per sample
 
 // SoA ray queue: 28 B per ray (origin, direction, pixel); inverse direction is recomputed. The seven planes of a
@@ -85,6 +86,10 @@ struct Control {
     uint32_t bounce;     // rows written this sample
     uint32_t samples;    // fused samples accumulated
     uint32_t _pad;
+    // class-binned fused loop (bounce_binned_kernel): hits of the last extend per cost class (0 once the loop has
+    // exited), the segments that extend wrote, and the segments the next one will write (= its hit work items)
+    uint32_t cls_n[kClsMax];
+    uint32_t n_segs, next_segs, _pad2[2];
     uint32_t rows[kMaxRows][4]; // (rays_in, hits, misses, shaded) per bounce of the current sample
     unsigned long long totals[4]; // rays traced, hits, misses, samples
     unsigned long long wave_totals[kMaxRows][3]; // per wavefront, over all fused samples: rays traced, hits, misses
@@ -100,7 +105,8 @@ struct ShadeRec {
     float albedo[3];
     float refract_index;
     uint32_t mat_type;
-    uint32_t _pad[3];
+    uint32_t cost_class; // class-binned loop: 0 = the scene's dominant primitive, 1 + material class otherwise (upload_scene)
+    uint32_t _pad[2];
 };
 
 struct SceneDev {
@@ -234,6 +240,48 @@ struct BounceArgs {
     uint32_t image_width;
     Tiling tile;
     SceneDev scene;
+    // ---- class-binned loop (bounce_binned_kernel): the hits of a segment are stored sorted by COST CLASS (ShadeRec::cost_class of the
+    // primitive hit), and a work item of the next launch is kChunk hits of ONE class (of one sample), found through the per-class tables
+    // the scan leaves. The PHYSICAL order of the queue is then no longer the reference's thread order, which shade's RNG is keyed by
+    // in WFPT_RNG_DISPATCH (sh:72). The logical order is carried instead: every ray has its thread index t of the reference's extend
+    // dispatch; extend leaves one flag byte per t (hit or not); the scan turns the flags into a rank table (per 64 thread indices: hits
+    // before them + the 64 hit bits); a hit record carries the t of the ray that made it, and the next launch recovers shade's thread
+    // index h = hits with a smaller t = prefix + popcount -- exactly the queue position ascending-order atomics (ex:59) give the hit.
+    const uint32_t *plan;           // [n * K + 1] first hit item of each (sample, class) | [n + 1] first segment item of each sample | [n + 1] first miss item
+    uint32_t plan_seg_off, plan_miss_off;
+    const uint2 *cls_table;         // in:  [n][segments][K] {class-k hits before this segment, first slot of the segment's class-k run}
+    const uint32_t *first_seg_cls;  // in:  [n][K][segments]: segment that holds class-k hit number kChunk * run
+    uint32_t *out_cls;              // out: [n][segments][words] per-segment class totals, packed 10 bits each (ClsPack)
+    const uint4 *rank_in;           // in (WFPT_RNG_DISPATCH): [n][capacity / 64] {hit bits 0-31, 32-63, hits before this group, -} of the previous extend
+    uint8_t *flag_out;              // out (WFPT_RNG_DISPATCH): [n][capacity] 1 = the ray with this thread index hit
+};
+
+// Packed counters of the class-binned compaction: field f of a word array sits in word f / 3 at bit 10 * (f % 3); a field holds at most
+// kChunk = 512 < 1024, so packed words add without carries between fields. Fields 0 .. K-1: hits per class, K: misses, K + 1: all hits.
+template <int K> struct ClsPack {
+    static constexpr int kFields = K + 2, kWords = (kFields + 2) / 3;
+};
+constexpr int kBinClasses = 4; // classes of the binned loop as built: 0 = the dominant primitive (the Shirley scene's ground), 1 + material type otherwise
+static_assert(kBinClasses <= kClsMax && kChunk <= 1023, "a packed field must hold a segment's count");
+
+struct ScanBinnedArgs {
+    Batch batch;
+    const uint32_t *chunk_hits, *chunk_miss, *chunk_cls; // per-segment totals of this wavefront (chunk_cls: ClsPack words)
+    uint2 *cls_table;
+    uint32_t *first_seg_cls;
+    const uint8_t *flags; // WFPT_RNG_DISPATCH: hit flag per thread index of this wavefront's extend (null: pixel-keyed RNG, the order is free)
+    uint4 *rank;          // ... and the rank table made of them
+    Control *ctl;
+    const uint32_t *n_in;
+    uint32_t limit, miss_floor, bounce;
+};
+
+struct PlanArgs {
+    Batch batch;
+    const Control *ctl;
+    uint32_t *plan;
+    uint32_t plan_seg_off, plan_miss_off;
+    uint32_t last; // 1: the next launch is the last one (shade without extend): its hit items are whole segments
 };
 
 // ---- HBM-resident scenes: traversal with dynamic lane refill. Rays of such scenes take very
@@ -339,6 +387,10 @@ hipError_t launch_generate(const GenerateArgs &a, hipStream_t s);
 hipError_t launch_extend(const ExtendArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s); // one workgroup per sample
 hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s);
+hipError_t launch_bounce_binned(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s); // LDS-resident scenes only
+hipError_t launch_scan_binned(const ScanBinnedArgs &a, hipStream_t s);
+hipError_t launch_plan(const PlanArgs &a, hipStream_t s);
+hipError_t bounce_binned_blocks_per_cu(const SceneDev &scene, int *blocks);
 hipError_t launch_refill(const RefillArgs &a, int mode, uint32_t grid, hipStream_t s, bool preshaded = false);
 hipError_t launch_shade_rays(const RefillArgs &a, uint32_t n_chunks, hipStream_t s);
 hipError_t launch_generate_dense(const RefillArgs &a, hipStream_t s); // the first wavefront's primary rays into the dense array (WFPT_PRESHADE)

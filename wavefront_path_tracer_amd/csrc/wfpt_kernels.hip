@@ -1397,6 +1397,25 @@ struct HitSource {
     uint32_t capacity, rng_mode, image_width, prim_kind;
     Tiling tile;
 };
+// shade of one path record (ra = hit point | pixel, rb = incoming direction | -), primitive `prim`, as the reference's shade thread h.
+// WAVE_SMP: the wave's lanes belong to one sample (its counters are scalars); WAVE_H: they hold 64 consecutive, 64-aligned h (shade_rng).
+template <bool SCATTER, bool WAVE_SMP, bool WAVE_H>
+__device__ __forceinline__ void shade_record(const HitSource &s, float4 ra, float4 rb, uint32_t prim, uint32_t h, wfpt_frame_buffer fb, float &ox,
+                                             float &oy, float &oz, float &dx, float &dy, float &dz, uint32_t &pixel_idx) {
+    pixel_idx = __float_as_uint(ra.w);
+    const float4 rec1 = s.shade_rec[3u * prim + 1u];
+    float4 *px = pixel_of(s.image, local_pixel(pixel_idx, s.image_width, s.tile));
+    const float4 thr = *px;
+    if (SCATTER) {
+        const float4 rec0 = s.shade_rec[3u * prim], rec2 = s.shade_rec[3u * prim + 2u];
+        const uint32_t gx = WAVE_SMP ? uniform(s.ctl->shade_gx) : s.ctl->shade_gx;
+        const uint32_t rng = shade_rng<WAVE_H>(s.rng_mode, h, gx, pixel_idx, fb);
+        const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), s.prim_kind);
+        ox = ra.x; oy = ra.y; oz = ra.z;
+        dx = ext.x; dy = ext.y; dz = ext.z;
+    }
+    *px = make_float4(thr.x * rec1.x, thr.y * rec1.y, thr.z * rec1.z, thr.w); // sh:84-87: throughput *= albedo, for every material type
+}
 // WAVE_RUN: every lane of the wave shades a hit of the same run of kChunk hits and the same sample (the fused bounce kernel), so the
 // run's segment bounds and the sample's counters are scalars.
 template <bool SCATTER, bool WAVE_RUN = false>
@@ -1412,20 +1431,7 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
     }
     const size_t slot = s.qo + static_cast<size_t>(lo) * kChunk + (h - s.in_hit_base[s.co + lo]);
     const float4 ra = s.rec_in[2u * slot], rb = s.rec_in[2u * slot + 1u];
-    pixel_idx = __float_as_uint(ra.w);
-    const uint32_t prim = __float_as_uint(rb.w);
-    const float4 rec1 = s.shade_rec[3u * prim + 1u];
-    float4 *px = pixel_of(s.image, local_pixel(pixel_idx, s.image_width, s.tile));
-    const float4 thr = *px;
-    if (SCATTER) {
-        const float4 rec0 = s.shade_rec[3u * prim], rec2 = s.shade_rec[3u * prim + 2u];
-        const uint32_t gx = WAVE_RUN ? uniform(s.ctl->shade_gx) : s.ctl->shade_gx;
-        const uint32_t rng = shade_rng<WAVE_RUN>(s.rng_mode, h, gx, pixel_idx, fb);
-        const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), s.prim_kind);
-        ox = ra.x; oy = ra.y; oz = ra.z;
-        dx = ext.x; dy = ext.y; dz = ext.z;
-    }
-    *px = make_float4(thr.x * rec1.x, thr.y * rec1.y, thr.z * rec1.z, thr.w);
+    shade_record<SCATTER, WAVE_RUN, WAVE_RUN>(s, ra, rb, __float_as_uint(rb.w), h, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
 }
 
 // ================================================================================================
@@ -1695,6 +1701,483 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         atomicAdd(&a.stamps[10], static_cast<unsigned long long>(acc_cnt[4]));
     }
 #endif
+}
+
+// ================================================================================================
+// Class-binned fused loop (round 4; LDS-resident scenes). bounce_kernel takes 512 CONSECUTIVE hits per work item, so
+// a wave holds rays that leave the ground next to rays that leave a marble, and lambertian next to dielectric hits: its while-while
+// traversal runs at 0.49 / 0.40 / 0.36 lane utilisation at bounces 1-3 and every wave runs every material branch of shade. Here the
+// hits of a segment are stored sorted by the COST CLASS of the primitive hit (ShadeRec::cost_class: 0 = the scene's dominant primitive,
+// 1 + material type otherwise; tests/model_binning.py scores the keys) -- K ballots instead of one, counts exchanged as packed 10-bit
+// fields, no atomics on the queues and nothing exchanged inside a work item; the scan leaves, per class, the running count in front of
+// every segment, and a work item of the next launch is 512 hits of ONE class of one sample.
+// The reference's ORDER survives although the storage loses it (BounceArgs::plan ff.): every ray knows its thread index t of the
+// reference's extend dispatch; extend leaves a hit flag per t; a hit record carries t (23 bits, packed above the pixel and primitive
+// indices); the scan turns the flags into the rank table and the next launch shades the record as the reference's shade thread
+// h = (hits with a smaller t), whose extension ray is extend thread h (sh:155 under ascending-order atomics). In WFPT_RNG_PIXEL nothing
+// depends on the order and the flags / rank table are skipped.
+// ================================================================================================
+constexpr uint32_t kBinPixelBits = 23, kBinPrimBits = 16; // record words: pixel | t[0:9) << 23, primitive | t[9:23) << 16
+template <int K> __device__ __forceinline__ uint32_t cls_field(const uint32_t *w, int f) { return (w[f / 3] >> (10 * (f % 3))) & 1023u; }
+
+template <int MODE, typename Trail, int PRIM, bool EXACT, int K>
+__global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_binned_kernel(BounceArgs a) {
+    extern __shared__ float4 lds[];
+    constexpr bool TRACE = MODE != kBounceLast;
+    constexpr int NW = ClsPack<K>::kWords;
+    constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u;
+    float4 *s_nodes = lds;
+    float4 *s_geom = lds + (TRACE ? 2u * a.scene.n_nodes : 0u);
+    const uint32_t parent_words = TRACE ? ((a.scene.n_nodes / 2u + 1u) + 7u) / 8u : 0u;
+    const uint32_t geom_words = TRACE ? kGeomWords * a.scene.n_spheres : 0u;
+    uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_geom + geom_words);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geom + geom_words + parent_words); // [2][kExtendWaves][NW] packed per-wave counts
+    uint32_t *s_next = s_cnt + 2 * kExtendWaves * NW;                                    // [2] next work item
+    uint8_t *s_cls = reinterpret_cast<uint8_t *>(s_next + 2);                            // [n_prims] cost class of each primitive (ShadeRec::cost_class)
+
+    const uint32_t nb = a.batch.n;
+    const uint32_t n_slots = a.gx * a.gy * 64u; // first wavefront: ray slots of this context's tiles
+    const uint32_t n_first = umin(n_slots, a.capacity), items_first = (n_first + kChunk - 1) / kChunk;
+    // work items: [0, n_hit_items) hit items -- first: (sample, 512 ray slots); middle: (sample, class, run of 512 hits of that class);
+    // last: (sample, segment) -- then the miss items (sample, kMissSegsPerItem segments), all numbered by the plan the scan's launch left
+    const uint32_t *plan_h = a.plan, *plan_m = a.plan + a.plan_miss_off;
+    if (MODE == kBounceLast) plan_h = a.plan + a.plan_seg_off;
+    const uint32_t n_hit_items = MODE == kBounceFirst ? items_first * nb : uniform(plan_h[MODE == kBounceLast ? nb : nb * K]);
+    const uint32_t n_items = MODE == kBounceFirst ? n_hit_items : uniform(plan_m[nb]);
+    if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < nb)
+        a.ctl[threadIdx.x].n_in = n_first; // pt:313-316: counter[2] = rays of the first wavefront (read by scan)
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
+    if (TRACE) {
+        const float4 *g_staged = EXACT ? g_nodes : a.scene.nodes_ch; // reference boxes, or conservative centre / half-extent boxes
+        for (uint32_t i = threadIdx.x; i < 2u * a.scene.n_nodes; i += kExtendThreads) s_nodes[i] = g_staged[i];
+        for (uint32_t i = threadIdx.x; i < geom_words; i += kExtendThreads) s_geom[i] = a.scene.prim_geom[i];
+        const uint4 *g_par = reinterpret_cast<const uint4 *>(a.scene.pair_parent);
+        uint4 *s_par4 = reinterpret_cast<uint4 *>(s_parent);
+        for (uint32_t i = threadIdx.x; i < parent_words; i += kExtendThreads) s_par4[i] = g_par[i];
+        for (uint32_t i = threadIdx.x; i < a.scene.n_spheres; i += kExtendThreads)
+            s_cls[i] = static_cast<uint8_t>(umin(__float_as_uint(a.scene.shade_rec[3u * i + 2u].y), static_cast<uint32_t>(K - 1)));
+        __syncthreads();
+    }
+    wfpt_frame_buffer fb0 = a.ctl->frame; // the same for every lane: kept in scalar registers
+    fb0.width = uniform(fb0.width); fb0.height = uniform(fb0.height); fb0.frame = uniform(fb0.frame); fb0.sample_number = uniform(fb0.sample_number);
+    const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6);
+    const bool keyed_by_order = a.rng_mode != WFPT_RNG_PIXEL; // the reference's RNG key: thread indices are carried, flags written
+    uint32_t idx_h = 0, idx_m = 0; // a workgroup's tickets only grow: the plan is searched on from where the previous item was found
+    uint32_t iter = 0;
+    while (item < n_items) {
+        const uint32_t buf = iter & 1u;
+        if (threadIdx.x == 0) s_next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        if (item >= n_hit_items) {
+            // ---------------- miss_kernel (mk:13-38) for kMissSegsPerItem segments of the previous wavefront's miss queue
+            while (item >= uniform(plan_m[idx_m + 1])) ++idx_m;
+            const uint32_t smp = idx_m;
+            const uint32_t first_seg = (item - uniform(plan_m[idx_m])) * kMissSegsPerItem;
+            const uint32_t n_segs = uniform(a.ctl[smp].n_segs);
+            const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+            float *image = a.image + smp * a.batch.image_stride;
+            for (uint32_t k = wave; k < kMissSegsPerItem; k += kExtendWaves) { // one segment per wave at a time
+                const uint32_t seg = first_seg + k;
+                if (seg >= n_segs) break;
+                const uint32_t count = uniform(a.in_miss[co + seg]);
+                for (uint32_t r = lane; r < count; r += 64u) {
+                    const size_t slot = qo + static_cast<size_t>(seg) * kChunk + r;
+                    const float dy = a.mq_in.dy()[slot]; // ray_buffer[miss_buffer[idx]].direction.y, mk:28-32
+                    const uint32_t pixel_idx = a.mq_in.pixel()[slot];
+                    const float t = 0.5f * (dy + 1.0f); // mk:32: the direction is not normalised after bounce 0
+                    const float om = 1.0f - t;
+                    const float cr = om * 1.0f + t * 0.5f; // mk:33
+                    const float cg = om * 1.0f + t * 0.7f;
+                    const float cb = om * 1.0f + t * 1.0f;
+                    float4 *px = pixel_of(image, local_pixel(pixel_idx, a.image_width, a.tile));
+                    const float4 thr = *px;
+                    *px = make_float4(thr.x * cr, thr.y * cg, thr.z * cb, thr.w); // mk:35-37
+                }
+            }
+            __syncthreads(); // s_next[buf] is visible
+            item = uniform(s_next[buf]);
+            iter += 1;
+            continue;
+        }
+        // ---------------- which rays: sample, output segment, and per lane the record (middle / last) or the ray slot (first)
+        uint32_t smp, seg_out;
+        bool live;
+        float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+        uint32_t pixel_idx = 0, tidx = 0; // tidx: this ray's thread index in the reference's extend dispatch of this wavefront
+        if (MODE == kBounceFirst) {
+            smp = item / items_first;
+            seg_out = item - smp * items_first;
+        } else if (MODE == kBounceMiddle) {
+            while (item >= uniform(plan_h[idx_h + 1])) ++idx_h;
+            smp = idx_h / K;
+            seg_out = item - uniform(plan_h[smp * K]);
+        } else {
+            while (item >= uniform(plan_h[idx_h + 1])) ++idx_h;
+            smp = idx_h;
+            seg_out = item - uniform(plan_h[idx_h]);
+        }
+        const size_t qo = smp * a.batch.queue_stride, co = smp * a.batch.chunk_stride;
+        float *image = a.image + smp * a.batch.image_stride;
+        wfpt_frame_buffer fb = fb0;
+        fb.frame += smp;
+        if (MODE == kBounceFirst) {
+            // ---------------- generate_rays (gr:42-91), true-size semantics: lanes outside the image emit nothing
+            const uint32_t h = seg_out * kChunk + threadIdx.x;
+            const uint32_t workgroup_index = uniform(h >> 6), local_index = h & 63u; // one wave = one 8x8 tile of generate_rays
+            const uint32_t wx = workgroup_index % a.gx, wy = workgroup_index / a.gx;
+            const uint32_t id_x = wx * 8u + (local_index & 7u);
+            const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
+            live = h < n_first && id_x < fb.width && id_y < fb.height;
+            tidx = h;
+            if (keyed_by_order && h < n_first && !live) a.flag_out[qo + h] = 0; // an inactive slot is a thread index without a hit
+            if (live) {
+                pixel_idx = id_x + id_y * fb.width; // gr:57
+                const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
+                ox = pr.ox; oy = pr.oy; oz = pr.oz; dx = pr.dx; dy = pr.dy; dz = pr.dz;
+                *pixel_of(image, local_pixel(pixel_idx, fb.width, a.tile)) = make_float4(1.0f, 1.0f, 1.0f, 1.0f); // pt:305-306 folded in: throughput starts at 1
+            }
+        } else {
+            // ---------------- the hit record of the previous wavefront this lane shades
+            const HitSource src{a.rec_in, nullptr, nullptr, a.ctl + smp, image, a.scene.shade_rec, qo, co,
+                                a.capacity, a.rng_mode, a.image_width, a.scene.prim_kind, a.tile};
+            size_t slot = 0;
+            if (MODE == kBounceMiddle) {
+                const uint32_t k = idx_h - smp * K, run = item - uniform(plan_h[idx_h]);
+                const uint32_t n_k = uniform(a.ctl[smp].cls_n[k]);
+                const uint32_t q = run * kChunk + threadIdx.x; // rank of this lane's hit among the sample's class-k hits
+                live = q < n_k;
+                if (live) {
+                    // its segment: the last one whose class-k count in front of it is not above q, between the segments that hold the
+                    // first hit of this run and of the next (the scan's first_seg table, per class)
+                    const uint32_t *fs = a.first_seg_cls + (static_cast<size_t>(smp) * K + k) * a.batch.chunk_stride;
+                    uint32_t lo = uniform(fs[run]);
+                    uint32_t hi = (run + 1u) * kChunk < n_k ? uniform(fs[run + 1u]) : uniform(a.ctl[smp].n_segs) - 1u;
+                    const uint2 *tab = a.cls_table + co * K + k; // the entry of segment s: tab[s * K]
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (tab[static_cast<size_t>(mid) * K].x <= q) lo = mid; else hi = mid - 1u;
+                    }
+                    const uint2 e = tab[static_cast<size_t>(lo) * K];
+                    slot = qo + e.y + (q - e.x);
+                }
+            } else { // last: whole segments, in storage order (shade only multiplies the throughput: no key, no order)
+                const uint32_t count = uniform(a.in_hits[co + seg_out]);
+                live = threadIdx.x < count;
+                slot = qo + static_cast<size_t>(seg_out) * kChunk + threadIdx.x;
+            }
+            if (live) {
+                float4 ra = a.rec_in[2u * slot];
+                const float4 rb = a.rec_in[2u * slot + 1u];
+                const uint32_t wa = __float_as_uint(ra.w), wb = __float_as_uint(rb.w);
+                const uint32_t prim = wb & ((1u << kBinPrimBits) - 1u);
+                ra.w = __uint_as_float(wa & ((1u << kBinPixelBits) - 1u));
+                uint32_t h = 0;
+                if (TRACE && keyed_by_order) { // shade's thread index: hits of the previous extend with a smaller thread index
+                    const uint32_t t_prev = (wa >> kBinPixelBits) | ((wb >> kBinPrimBits) << (32u - kBinPixelBits));
+                    const uint4 g = a.rank_in[(qo >> 6) + (t_prev >> 6)];
+                    const uint32_t bit = t_prev & 63u;
+                    const uint32_t below_lo = bit >= 32u ? g.x : (g.x & ((1u << bit) - 1u));
+                    const uint32_t below_hi = bit > 32u ? (g.y & ((1u << (bit - 32u)) - 1u)) : 0u;
+                    h = g.z + static_cast<uint32_t>(__popc(below_lo)) + static_cast<uint32_t>(__popc(below_hi));
+                }
+                tidx = h; // shade thread h writes extension ray h (sh:155): extend's thread index
+                shade_record<TRACE, true, false>(src, ra, rb, prim, h, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
+            }
+        }
+        if (!TRACE) {
+            __syncthreads();
+            item = uniform(s_next[buf]);
+            iter += 1;
+            continue;
+        }
+        // ---------------- extend (ex:47-70) of the ray in registers
+#if WFPT_STAMPS
+        uint32_t dbg[3] = {0, 0, 0};
+#endif
+        float t = 0.0f;
+        uint32_t prim = 0;
+        bool hit = false;
+        if (live) {
+            if (EXACT)
+                hit = trace_ray<Trail, PRIM, uint16_t, 0, true>(s_nodes, s_geom, s_parent, nullptr, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            else {
+                prim = kHandOver;
+                if (!far_origin(a.scene, ox, oy, oz))
+                    hit = trace_ray_conservative<Trail, PRIM, uint16_t>(s_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim WFPT_DBG_ARG);
+                if (prim == kHandOver) // near-tie, failed verdict or far origin: the reference's own walk decides (its boxes are read from global memory: this is rare)
+                    hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
+            }
+        }
+        const bool miss = live && !hit;
+        // ---------------- compaction, class by class: K ballots, per-wave counts as packed fields, one LDS exchange
+        uint32_t cls = K; // no hit
+        if (hit) cls = s_cls[prim]; // ShadeRec::cost_class
+        if (keyed_by_order && live) a.flag_out[qo + tidx] = hit ? 1 : 0;
+        const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
+        uint32_t wcnt[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) wcnt[j] = 0;
+        uint32_t rank = 0; // this lane's rank among the wave's lanes of its class
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __ballot(cls == static_cast<uint32_t>(k));
+            wcnt[k / 3] |= static_cast<uint32_t>(__popcll(m)) << (10 * (k % 3));
+            rank = cls == static_cast<uint32_t>(k) ? mbcnt(m) : rank;
+        }
+        wcnt[K / 3] |= static_cast<uint32_t>(__popcll(miss_mask)) << (10 * (K % 3));
+        wcnt[(K + 1) / 3] |= static_cast<uint32_t>(__popcll(hit_mask)) << (10 * ((K + 1) % 3));
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) s_cnt[(buf * kExtendWaves + wave) * NW + j] = wcnt[j];
+        }
+        __syncthreads();
+        uint32_t before[NW], total[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { before[j] = 0; total[j] = 0; }
+#pragma unroll
+        for (uint32_t w = 0; w < kExtendWaves; ++w) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const uint32_t v = uniform(s_cnt[(buf * kExtendWaves + w) * NW + j]);
+                before[j] += (w < wave) ? v : 0u; // fields of at most 512 each: no carries between them
+                total[j] += v;
+            }
+        }
+        // where class k starts inside the segment: the totals of the classes before it (packed like the counts)
+        uint32_t coff[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) coff[j] = 0;
+        uint32_t run_off = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            coff[k / 3] |= run_off << (10 * (k % 3));
+            run_off += cls_field<K>(total, k);
+        }
+        const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
+        if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel -- and the thread index
+            const uint32_t wsel = cls / 3u, sh = 10u * (cls - 3u * wsel);
+            uint32_t wb = before[0], wc = coff[0];
+#pragma unroll
+            for (int j = 1; j < NW; ++j) { wb = wsel == static_cast<uint32_t>(j) ? before[j] : wb; wc = wsel == static_cast<uint32_t>(j) ? coff[j] : wc; }
+            const size_t slot = seg + ((wc >> sh) & 1023u) + ((wb >> sh) & 1023u) + rank;
+            const uint32_t tt = keyed_by_order ? tidx : 0u;
+            a.rec_out[2u * slot] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(pixel_idx | (tt << kBinPixelBits)));
+            a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim | ((tt >> (32u - kBinPixelBits)) << kBinPrimBits)));
+        }
+        if (miss) { // what miss_kernel reads of the ray (mk:29-32)
+            const size_t slot = seg + cls_field<K>(before, K) + mbcnt(miss_mask);
+            a.mq_out.dy()[slot] = dy;
+            a.mq_out.pixel()[slot] = pixel_idx;
+        }
+        if (threadIdx.x == 0) {
+            a.out_hits[co + seg_out] = cls_field<K>(total, K + 1);
+            a.out_miss[co + seg_out] = cls_field<K>(total, K);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) a.out_cls[(co + seg_out) * NW + j] = total[j];
+        }
+        item = uniform(s_next[buf]);
+        iter += 1;
+    }
+}
+
+// ---- scan of the class-binned loop: one workgroup per sample. Per class the running count in front of every segment (and where the
+// class's run starts inside the segment), the segment that holds the first hit of every run of kChunk hits of a class, the counter
+// protocol and loop exit of scan_kernel (pt:327-353), and -- dispatch-keyed RNG -- the rank table made of extend's hit flags.
+template <int K>
+__global__ __launch_bounds__(kScanThreads) void scan_binned_kernel(ScanBinnedArgs a) {
+    constexpr int NW = ClsPack<K>::kWords, NQ = K + 2; // scanned quantities: K classes, all hits, misses
+    __shared__ uint32_t s_wave[NQ][kScanThreads / 64];
+    __shared__ uint32_t s_fac;
+    const uint32_t sample = blockIdx.x;
+    Control *c = a.ctl + sample;
+    const size_t co = static_cast<size_t>(sample) * a.batch.chunk_stride;
+    const uint32_t *chunk_hits = a.chunk_hits + co, *chunk_miss = a.chunk_miss + co, *chunk_cls = a.chunk_cls + co * NW;
+    uint2 *cls_table = a.cls_table + co * K;
+    uint32_t *first_seg_cls = a.first_seg_cls + co * K;
+    const uint32_t n = umin(a.n_in[static_cast<size_t>(sample) * a.batch.ctl_stride], a.limit);
+    // segments this wavefront's extend wrote: the first one 512 ray slots each, later ones one per hit work item (plan_kernel's count)
+    const uint32_t n_chunks = a.bounce == 0 ? (n + kChunk - 1) / kChunk : (n == 0 ? 0u : c->next_segs);
+    const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6);
+    // ---- hit flags -> rank table (thread-contiguous chunks of 64-flag groups: count, block prefix, then the groups' own prefixes)
+    if (a.flags && n > 0) {
+        const uint8_t *flags = a.flags + static_cast<size_t>(sample) * a.batch.queue_stride;
+        uint4 *rank = a.rank + (static_cast<size_t>(sample) * a.batch.queue_stride >> 6);
+        const uint32_t n_groups = (n + 63u) / 64u, per = (n_groups + kScanThreads - 1) / kScanThreads;
+        const uint32_t g0 = umin(threadIdx.x * per, n_groups), g1 = umin(g0 + per, n_groups);
+        uint32_t count = 0;
+        for (uint32_t g = g0; g < g1; ++g) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(flags + static_cast<size_t>(g) * 64u);
+            uint32_t bits[2] = {0u, 0u};
+#pragma unroll
+            for (uint32_t v = 0; v < 4; ++v) {
+                uint4 w = p[v];
+                if (g * 64u + v * 16u + 16u > n) { // the queue's tail: flags beyond the last ray are stale
+                    uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                    for (uint32_t b = 0; b < 16; ++b)
+                        if (g * 64u + v * 16u + b >= n) ww[b >> 2] &= ~(0xffu << (8u * (b & 3u)));
+                    w = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+                }
+                // four flag bytes (0 / 1) of a word -> four bits: ((x & 0x01010101) * 0x10204080) >> 28 (byte k lands on bit 28 + k, no carries)
+                const uint32_t n0 = ((w.x & 0x01010101u) * 0x10204080u) >> 28, n1 = ((w.y & 0x01010101u) * 0x10204080u) >> 28;
+                const uint32_t n2 = ((w.z & 0x01010101u) * 0x10204080u) >> 28, n3 = ((w.w & 0x01010101u) * 0x10204080u) >> 28;
+                bits[v >> 1] |= (n0 | (n1 << 4) | (n2 << 8) | (n3 << 12)) << (16u * (v & 1u));
+            }
+            rank[g] = make_uint4(bits[0], bits[1], 0u, 0u);
+            count += static_cast<uint32_t>(__popc(bits[0])) + static_cast<uint32_t>(__popc(bits[1]));
+        }
+        const uint32_t inc = wave_inclusive_scan(count);
+        if (lane == 63) s_wave[0][wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - count;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) before += (w < wave) ? s_wave[0][w] : 0u;
+        for (uint32_t g = g0; g < g1; ++g) { // (this thread's own stores: visible to itself)
+            uint4 e = rank[g];
+            e.z = before;
+            rank[g] = e;
+            before += static_cast<uint32_t>(__popc(e.x)) + static_cast<uint32_t>(__popc(e.y));
+        }
+        __syncthreads();
+    }
+    // ---- per-class prefixes over the segments
+    uint32_t carry[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) carry[q] = 0;
+    for (uint32_t base = 0; base < n_chunks; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v[NQ], inc[NQ];
+        uint32_t words[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) words[j] = i < n_chunks ? chunk_cls[static_cast<size_t>(i) * NW + j] : 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = cls_field<K>(words, k);
+        v[K] = i < n_chunks ? chunk_hits[i] : 0u;
+        v[K + 1] = i < n_chunks ? chunk_miss[i] : 0u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            inc[q] = wave_inclusive_scan(v[q]);
+            if (lane == 63) s_wave[q][wave] = inc[q];
+        }
+        __syncthreads();
+        uint32_t before[NQ], tile[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { before[q] = 0; tile[q] = 0; }
+#pragma unroll
+        for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t x = s_wave[q][w];
+                before[q] += (w < wave) ? x : 0u;
+                tile[q] += x;
+            }
+        }
+        if (i < n_chunks) {
+            uint32_t off = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t bk = carry[k] + before[k] + inc[k] - v[k];
+                cls_table[static_cast<size_t>(i) * K + k] = make_uint2(bk, i * kChunk + off);
+                if (v[k] > 0) { // a segment holds at most kChunk hits of a class, so at most one multiple of kChunk
+                    const uint32_t m = (bk + kChunk - 1) / kChunk;
+                    if (m * kChunk < bk + v[k]) first_seg_cls[static_cast<size_t>(k) * a.batch.chunk_stride + m] = i;
+                }
+                off += v[k];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) carry[q] += tile[q];
+        __syncthreads();
+    }
+    const uint32_t hits = carry[K], misses = carry[K + 1];
+    // x extent of workgroup_size_64(hits) (pt:282-289), the dispatch shape shade.wgsl:72 keys its RNG on
+    const uint32_t q = (hits + 63u) / 64u;
+    uint32_t gx = 1;
+    if (q > 1) {
+        const uint32_t y = static_cast<uint32_t>(__builtin_ceilf(sqrt_(static_cast<float>(q))));
+        if (threadIdx.x == 0) s_fac = 1u;
+        __syncthreads();
+        for (int z = static_cast<int>(y) - 1 - static_cast<int>(threadIdx.x); z >= 1; z -= kScanThreads) {
+            if (q % static_cast<uint32_t>(z) == 0u) {
+                atomicMax(&s_fac, static_cast<uint32_t>(z));
+                break;
+            }
+        }
+        __syncthreads();
+        const uint32_t fac = s_fac;
+        gx = (q / fac >= (1u << 16)) ? y : fac;
+    }
+    __syncthreads(); // every thread has read c->next_segs before thread 0 replaces it
+    if (threadIdx.x == 0) {
+        c->seg_n = n;
+        c->n_segs = n_chunks;
+        c->hits = hits;
+        c->misses = misses;
+        c->shade_gx = gx;
+        if (sample == 0) c->ticket = 0; // the work-item ticket lives in the first Control block
+        uint32_t done = (a.bounce == 0) ? 0u : c->done;
+        const uint32_t ran = done ? 0u : 1u;       // this wavefront's extend really ran
+        if (!done && misses < a.miss_floor) done = 1; // pt:332: exit before shading
+        c->done = done;
+        c->shade_n = done ? 0u : hits;
+        c->miss_n = done ? 0u : misses;
+        c->n_in = done ? 0u : hits; // every shaded hit emits exactly one extension ray (sh:155)
+        uint32_t next = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            c->cls_n[k] = done ? 0u : carry[k];
+            next += done ? 0u : (carry[k] + kChunk - 1) / kChunk;
+        }
+        c->next_segs = next; // the next extend writes one segment per hit work item
+        c->counters[0] = misses;
+        c->counters[1] = hits;
+        c->counters[2] = done ? n : 0u; // pt:335-336
+        if (a.bounce < kMaxRows) {
+            c->rows[a.bounce][0] = ran ? n : 0u;
+            c->rows[a.bounce][1] = hits;
+            c->rows[a.bounce][2] = misses;
+            c->rows[a.bounce][3] = (ran && !done) ? 1u : 0u;
+        }
+        c->bounce = a.bounce + 1;
+    }
+}
+
+// ---- the work-item plan of the next launch of the class-binned loop: exclusive prefixes over (sample, class) hit items, over the
+// samples' segments (the last launch shades whole segments) and over the samples' miss items, which follow the hit items
+__device__ __forceinline__ uint32_t block_exclusive_scan_512(uint32_t v, uint32_t *s_part, uint32_t &total) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - v;
+    total = 0;
+    for (uint32_t w = 0; w < 8; ++w) {
+        const uint32_t x = s_part[w];
+        before += (w < wave) ? x : 0u;
+        total += x;
+    }
+    return before;
+}
+template <int K>
+__global__ __launch_bounds__(512) void plan_kernel(PlanArgs a) {
+    __shared__ uint32_t s_part[8];
+    const uint32_t t = threadIdx.x, nb = a.batch.n; // nb * K <= 512 (kMaxBatch samples, kBinClasses classes)
+    uint32_t total_h = 0, total_s = 0, total_m = 0;
+    uint32_t v = 0;
+    if (t < nb * K) v = (a.ctl[t / K].cls_n[t % K] + kChunk - 1) / kChunk;
+    const uint32_t ex_h = block_exclusive_scan_512(v, s_part, total_h);
+    if (t < nb * K) a.plan[t] = ex_h;
+    if (t == 0) a.plan[nb * K] = total_h;
+    v = (t < nb && a.ctl[t].shade_n > 0) ? a.ctl[t].n_segs : 0u;
+    const uint32_t ex_s = block_exclusive_scan_512(v, s_part, total_s);
+    if (t < nb) a.plan[a.plan_seg_off + t] = ex_s;
+    if (t == 0) a.plan[a.plan_seg_off + nb] = total_s;
+    v = (t < nb && a.ctl[t].miss_n > 0) ? (a.ctl[t].n_segs + kMissSegsPerItem - 1) / kMissSegsPerItem : 0u;
+    const uint32_t ex_m = block_exclusive_scan_512(v, s_part, total_m);
+    const uint32_t first = a.last ? total_s : total_h;
+    if (t < nb) a.plan[a.plan_miss_off + t] = first + ex_m;
+    if (t == 0) a.plan[a.plan_miss_off + nb] = first + total_m;
 }
 
 // ================================================================================================
@@ -2212,6 +2695,59 @@ hipError_t bounce_blocks_per_cu(const SceneDev &scene, int *blocks) {
             }
     }
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, bounce_variant(scene, kBounceMiddle), kExtendThreads, bytes);
+}
+
+// ---- class-binned loop
+namespace {
+uint32_t bounce_binned_lds(const SceneDev &sc, int mode) {
+    const uint32_t misc = 4u * (2u * kExtendWaves * ClsPack<kBinClasses>::kWords + 2u + 2u) + ((sc.n_spheres + 15u) & ~15u);
+    if (mode == kBounceLast) return misc;
+    const uint32_t parent_words = ((sc.n_nodes / 2u + 1u) + 7u) / 8u;
+    return 32u * sc.n_nodes + 16u * (sc.prim_kind == 0 ? 1u : 3u) * sc.n_spheres + 16u * parent_words + misc;
+}
+template <int MODE, int PRIM, bool EXACT> BounceFn bounce_binned_pick(bool deep) {
+    return deep ? bounce_binned_kernel<MODE, unsigned long long, PRIM, EXACT, kBinClasses> : bounce_binned_kernel<MODE, uint32_t, PRIM, EXACT, kBinClasses>;
+}
+template <bool EXACT> BounceFn bounce_binned_variant_of(const SceneDev &sc, int mode) {
+    const bool deep = sc.depth > 31u;
+    if (sc.prim_kind == 0) return mode == kBounceFirst ? bounce_binned_pick<kBounceFirst, 0, EXACT>(deep) : bounce_binned_pick<kBounceMiddle, 0, EXACT>(deep);
+    return mode == kBounceFirst ? bounce_binned_pick<kBounceFirst, 1, EXACT>(deep) : bounce_binned_pick<kBounceMiddle, 1, EXACT>(deep);
+}
+BounceFn bounce_binned_variant(const SceneDev &sc, int mode) {
+    if (mode == kBounceLast) return bounce_binned_kernel<kBounceLast, uint32_t, 0, false, kBinClasses>; // no traversal: one variant
+    return sc.exact ? bounce_binned_variant_of<true>(sc, mode) : bounce_binned_variant_of<false>(sc, mode);
+}
+} // namespace
+
+hipError_t bounce_binned_blocks_per_cu(const SceneDev &scene, int *blocks) {
+    const uint32_t bytes = bounce_binned_lds(scene, kBounceMiddle);
+    if (bytes > 64u * 1024u) {
+        for (int exact = 0; exact < 2; ++exact)
+            for (int mode : {kBounceFirst, kBounceMiddle}) {
+                SceneDev sc = scene;
+                sc.exact = static_cast<uint32_t>(exact);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bounce_binned_variant(sc, mode)),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+                if (e != hipSuccess) return e;
+            }
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, bounce_binned_variant(scene, kBounceMiddle), kExtendThreads, bytes);
+}
+
+hipError_t launch_bounce_binned(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s) {
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(bounce_binned_variant(a.scene, mode), dim3(grid), dim3(kExtendThreads), bounce_binned_lds(a.scene, mode), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_binned(const ScanBinnedArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(scan_binned_kernel<kBinClasses>, dim3(a.batch.n), dim3(kScanThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_plan(const PlanArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(plan_kernel<kBinClasses>, dim3(1), dim3(512), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_bounce(const BounceArgs &a, int mode, uint32_t grid, hipStream_t s) {
