@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-lds-scene", action="store_true", help="experiment: traverse the scene from HBM / L2 although it fits LDS")
     ap.add_argument("--no-binning", action="store_true",
                     help="WFPT_FLAG_NO_BINNING (pixel-keyed RNG): the hit queue stays in thread order (a work item = 512 consecutive hits) instead of being binned by cost class")
+    ap.add_argument("--two-chains", action="store_true", help="WFPT_FLAG_TWO_CHAINS (experiment): a batch as two overlapping half-batches on two streams")
     ap.add_argument("--binning", action="store_true",
                     help="WFPT_FLAG_BINNING: the class-binned loop in the dispatch-keyed RNG mode too (thread indices carried; same image, slower there)")
     ap.add_argument("--no-refill", action="store_true", help="mesh scene: fused bounce kernel (lanes keep their ray) instead of dynamic lane refill")
@@ -160,7 +161,10 @@ def provenance(W, gpu_index):
     info = _build.build_info()
     try:
         import torch
-        dev = {"name": torch.cuda.get_device_name(gpu_index)}
+        name = torch.cuda.get_device_name(gpu_index) or ""
+        arch = getattr(torch.cuda.get_device_properties(gpu_index), "gcnArchName", "")
+        hw = W.device_info(gpu_index)
+        dev = {"name": f"{name or 'AMD GPU'} ({arch}, {hw['compute_units']} CUs, {hw['total_memory_bytes'] >> 30} GiB)"}
     except Exception:
         dev = {"name": None}
     return {"command": "python " + " ".join([os.path.basename(sys.argv[0])] + sys.argv[1:]),
@@ -220,7 +224,7 @@ def main():
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
              (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0) |
              (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0) |
-             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0) | (W.FLAG_NO_BINNING if args.no_binning else 0) | (W.FLAG_BINNING if args.binning else 0))
+             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0) | (W.FLAG_NO_BINNING if args.no_binning else 0) | (W.FLAG_BINNING if args.binning else 0) | (W.FLAG_TWO_CHAINS if args.two_chains else 0))
     # samples in flight per launch = the whole frame's samples (64): the late wavefronts are small, and a launch of few work
     # items per workgroup ends on a long tail (32 / 64 / 128 in flight: 18.8 / 19.4 / 19.6 Grays/s on a 128-spp job)
     fused = not (args.split_shade or args.unfused)

@@ -196,12 +196,17 @@ enum {
     WFPT_FLAG_NO_BINNING = 1u << 7,  /* WFPT_RNG_PIXEL, scenes in LDS: keep the hit queue in thread order (a work item of the fused
                                         loop = 512 consecutive hits) instead of storing every segment's hits sorted by cost class
                                         (the dominant primitive | material) and shading / tracing 512 hits of ONE class per work
-                                        item, which is the default there (+2.3 % measured). Same images bit for bit. */
-    WFPT_FLAG_BINNING = 1u << 8      /* run the class-binned loop in WFPT_RNG_DISPATCH too. The reference's order survives -- every
+                                        item, which is the default there for contexts of at least 3/4 Mpixel (+2.3 % measured at
+                                        1920x1080; smaller slabs lose to the partly filled work items). Same images bit for bit. */
+    WFPT_FLAG_BINNING = 1u << 8,     /* run the class-binned loop whatever the size, and in WFPT_RNG_DISPATCH too. The reference's order survives -- every
                                         ray carries its thread index, extend leaves a hit flag per thread index, the scan turns
                                         the flags into a rank table and shade's thread index (shade.wgsl:72) is recovered from it
                                         -- so the images are the same bit for bit; but carrying the order costs what the binning
                                         gains (-5.8 % measured), hence off by default. */
+    WFPT_FLAG_TWO_CHAINS = 1u << 9   /* experiment: run a batch of the fused loop as its two halves, two chains of launches on two
+                                        streams (two branches of the captured graph), so that the tail of one half's launch
+                                        overlaps with the bulk of the other's. Samples are independent: same images bit for bit.
+                                        Measured slower at every slab size (profiles/r04_rejected_experiments.txt): off by default. */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu

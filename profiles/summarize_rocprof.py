@@ -29,6 +29,8 @@ import shutil
 import sys
 
 NAMES = [("bounce_kernel<0", "bounce_first"), ("bounce_kernel<1", "bounce"), ("bounce_kernel<2", "bounce_last"),
+         ("bounce_binned_kernel<0", "bounce_first"), ("bounce_binned_kernel<1", "bounce"), ("bounce_binned_kernel<2", "bounce_last"),
+         ("scan_binned_kernel", "scan"), ("plan_kernel", "plan"),
          ("refill_kernel<0", "bounce_first"), ("refill_kernel<1", "bounce"), ("compact_kernel", "compact"),
          ("extend_kernel", "extend"), ("shade_kernel", "shade"), ("shade_rays_kernel", "shade_rays"), ("miss_kernel", "miss_kernel"), ("scan_kernel", "scan"),
          ("generate_rays_kernel", "generate_rays"), ("generate_dense_kernel", "generate_rays"), ("accumulate_kernel", "accumulate")]
@@ -111,7 +113,8 @@ def main():
     frames = max(steps, 1)
     rays_per_launch = {"bounce_first": (wr[0] / frames) if wr else None,
                        "bounce": (sum(wr[1:]) / frames / max(len(wr) - 1, 1)) if len(wr) > 1 else None}
-    needles = {"bounce": ("bounce_kernel<1", "refill_kernel<1"), "bounce_first": ("bounce_kernel<0", "refill_kernel<0"), "extend": ("extend_kernel",)}
+    needles = {"bounce": ("bounce_kernel<1", "refill_kernel<1", "bounce_binned_kernel<1"),
+               "bounce_first": ("bounce_kernel<0", "refill_kernel<0", "bounce_binned_kernel<0"), "extend": ("extend_kernel",)}
     gather_shape = scene == "mesh" and "nolds" not in variant and "norefill" not in variant  # the refill traversal: per-lane 4 x 16 B node fetches
     for dom in ("bounce", "bounce_first", "extend"):
         k = out.get(dom)

@@ -250,3 +250,50 @@ def adversarial_rays_mesh(W, tris, nodes, n_max):
         out["inv_direction"] = (np.float32(1.0) / out["direction"][:, :3]).astype("<f4")
     out["pixel_idx"] = np.arange(len(out), dtype="<u4") % 1024
     return out
+
+
+def grazing_rays_mesh(W, tris, n_max, seed=11):
+    """Rays for which Moeller-Trumbore is worst conditioned: within 1e-7 .. 1e-2 rad of a triangle's plane, passing
+    an edge at -1e-3 .. +1e-3 (relative to the edge's length; negative = inside) as seen in the plane. The rounding slack of the
+    primitive test grows like 1 / (cos(angle to the normal) * sin(angle between the edges)): such rays are where a hit could be reported
+    for a ray that passes outside the triangle's box by more than the free walks' margin."""
+    rng = np.random.default_rng(seed)
+    rays = []
+    per = max(n_max // 12, 1)
+    for k in rng.permutation(len(tris))[:per]:
+        a = tris["v0"][k].astype(np.float64)
+        e1, e2 = tris["e1"][k].astype(np.float64), tris["e2"][k].astype(np.float64)
+        nrm = np.cross(e1, e2)
+        ln = np.linalg.norm(nrm)
+        if ln == 0:
+            continue
+        nrm /= ln
+        for (p0, ed) in ((a, e1), (a, e2), (a + e1, e2 - e1)):
+            le = np.linalg.norm(ed)
+            if le == 0:
+                continue
+            along = ed / le
+            out = np.cross(along, nrm)                      # in the plane, perpendicular to the edge
+            if np.dot(out, (a + (e1 + e2) / 3.0) - p0) > 0:  # make it point away from the triangle
+                out = -out
+            for _ in range(4):
+                s = rng.uniform(0.05, 0.95)
+                off = rng.choice([-1e-3, -1e-5, -1e-7, 0.0, 1e-7, 1e-5, 1e-3]) * le
+                tilt = 10.0 ** rng.uniform(-7, -2) * rng.choice([-1.0, 1.0])
+                phi = rng.uniform(0, 2 * np.pi)
+                d_in_plane = np.cos(phi) * along + np.sin(phi) * out
+                d = d_in_plane + tilt * nrm
+                d /= np.linalg.norm(d)
+                target = p0 + s * ed + off * out
+                dist = rng.uniform(2.0, 40.0)
+                rays.append(((target - d * dist).astype(np.float32), d.astype(np.float32)))
+    rays = rays[:n_max]
+    res = np.zeros(len(rays), W.RAY)
+    for k, (o, d) in enumerate(rays):
+        res["origin"][k, :3] = o
+        res["origin"][k, 3] = 1.0
+        res["direction"][k, :3] = d
+    with np.errstate(all="ignore"):
+        res["inv_direction"] = (np.float32(1.0) / res["direction"][:, :3]).astype("<f4")
+    res["pixel_idx"] = np.arange(len(res), dtype="<u4") % 1024
+    return res

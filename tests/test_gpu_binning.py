@@ -90,6 +90,7 @@ def test_binned_loop_in_band_shards(gpu, orc):
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, rng_mode=1, max_wavefronts=bounces, miss_floor=0)
     want = o.render(spp)
     cc = W.CameraController(W.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
-    acc = W.render_chunked(W.Scene.book_one_final(1), W.RenderParameters(cc, (w, h)), spp, 3, max_wavefronts=bounces, rng_mode=W.RNG_PIXEL, miss_floor=0)
+    acc = W.render_chunked(W.Scene.book_one_final(1), W.RenderParameters(cc, (w, h)), spp, 3, max_wavefronts=bounces, rng_mode=W.RNG_PIXEL, miss_floor=0,
+                           flags=W.FLAG_BINNING)  # (slabs this small keep the thread-ordered queue by default)
     assert_bit_equal(acc, want, "3 band shards, binned")
     o.close()

@@ -333,7 +333,8 @@ def test_batched_samples_equal_sequential(gpu, orc, batch):
     w, h, spp, bounces = 200, 120, 19, 5  # 19 = full batches plus a remainder rendered one by one
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED, W.FLAG_BINNING):
+    # (WFPT_FLAG_TWO_CHAINS: the batch's halves as two chains of launches on two streams; with and without a captured graph)
+    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED, W.FLAG_BINNING, W.FLAG_TWO_CHAINS, W.FLAG_TWO_CHAINS | W.FLAG_NO_GRAPH, W.FLAG_TWO_CHAINS | W.FLAG_BINNING):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")

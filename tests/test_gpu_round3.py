@@ -141,6 +141,40 @@ def test_adversarial_rays_on_a_mesh(gpu, orc, where, exact):
     pt.close(); o.close()
 
 
+@pytest.mark.parametrize("where,n_tri,scale", [("lds", 1200, 12.0), ("hbm", 1200, 12.0), ("hbm", 30000, 3.0)])
+def test_grazing_rays_on_a_mesh(gpu, orc, where, n_tri, scale):
+    """Where Moeller-Trumbore is worst conditioned (helpers.grazing_rays_mesh: within 1e-7 .. 1e-2 rad of a triangle's
+    plane, passing an edge at +-1e-7 .. 1e-3 edge lengths): the device's free walks (LDS-resident binary walk; four-wide walk from HBM)
+    against the oracle's hit and miss queues, bit for bit. The CPU models of the same walks: tests/test_traversal_model.py."""
+    from helpers import grazing_rays_mesh
+    W = gpu
+    w, h = 256, 128
+    tris, mt = orc.scene_random_mesh(n_tri, 1)
+    tris["e1"] *= np.float32(scale); tris["e2"] *= np.float32(scale)
+    tris_o, nodes = orc.build_bvh_triangles(tris, 32)
+    cam, ip, vw = orc.mesh_camera(w, h)
+    o = orc.Oracle(w, h, np.zeros(1, orc.SPHERE), mt, nodes, cam, ip, vw, triangles=tris_o)
+    scene = W.Scene.random_mesh(n_tri, 1)
+    scene.triangles["e1"] *= np.float32(scale); scene.triangles["e2"] *= np.float32(scale)
+    cc = W.CameraController(W.Camera((0.0, 0.0, 30.0), (0.0, 0.0, 0.0)), 40.0, 0.0, 10.0, 0.1, 100.0)
+    pt = W.PathTracer(scene, W.RenderParameters(cc, (w, h)), mesh_bins=32, flags=W.FLAG_NO_LDS_SCENE if where == "hbm" else 0)
+    assert_bit_equal(pt.bvh_tree.nodes, nodes.view(W.BVH_NODE), "host BVH")
+    rays = grazing_rays_mesh(W, tris_o, w * h)
+    n = len(rays)
+    pt.set_frame(W.GPUFrameBuffer.new(w, h, 1)); o.set_frame(1, 0)
+    pt.write_rays(rays); o.write_rays(rays.view(orc.RAY))
+    pt.set_counters([0, 0, n]); o.set_counters([0, 0, n])
+    ext = W.workgroup_size_64(n)
+    pt.extend_kernel.run(ext); o.extend(*ext)
+    c = o.counters()
+    assert np.array_equal(pt.read_counters()[:3], c[:3]), f"{pt.read_counters()[:3]} vs {c[:3]}"
+    misses, hits = int(c[0]), int(c[1])
+    assert hits > n // 20 and misses > n // 20
+    assert_bit_equal(pt.hits(hits), o.hits(hits).view(W.HIT), f"hit queue of the grazing rays ({where}, {n_tri} triangles)")
+    assert_bit_equal(pt.misses(misses), o.misses(misses), "miss queue of the grazing rays")
+    pt.close(); o.close()
+
+
 def test_far_origins_switch_the_stage_extend_to_the_exact_test(gpu, orc):
     """Origins beyond four scene extents leave the range the conservative margin was sized for: wfpt_write_rays switches the
     context's extend to the reference's own box test; results stay the oracle's."""

@@ -61,7 +61,7 @@ def test_mesh_device_loop(gpu, orc, n_tris, scale, w, h):
     # binary tree as it is: all four must give the oracle's image
     # (scenes beyond LDS additionally trace with dynamic lane refill by default; WFPT_FLAG_NO_REFILL = the fused bounce kernel)
     for batch, flags in ((1, 0), (4, 0), (4, W.FLAG_NO_REFILL), (4, W.FLAG_BINARY_BVH), (4, W.FLAG_UNFUSED),
-                         (2, W.FLAG_UNFUSED | W.FLAG_BINARY_BVH)):
+                         (2, W.FLAG_UNFUSED | W.FLAG_BINARY_BVH), (4, W.FLAG_TWO_CHAINS), (5, W.FLAG_TWO_CHAINS | W.FLAG_NO_REFILL)):
         pt = make_mesh_tracer(W, w, h, n_tris, scale, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"mesh image, batch {batch}, flags {flags}")
@@ -143,7 +143,9 @@ def test_config5_full_size_against_golden(gpu, mode):
     W = gpu
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"mesh1m_1920x1080_mode{mode}.npz"))
     w, h, bounces, n_tri = int(g["width"]), int(g["height"]), int(g["bounces"]), int(g["n_triangles"])
-    for flags in (0, W.FLAG_UNFUSED):
+    # (WFPT_FLAG_EXACT_TRAVERSAL: the reference's own walk over the caller's binary tree for every ray of the frame -- the four-wide
+    # free walk with its leaf-box verdicts and hand-overs, and the walk it hands over to, give the same golden)
+    for flags in (0, W.FLAG_UNFUSED, W.FLAG_EXACT_TRAVERSAL):
         pt = W.mesh_path_tracer(w, h, n_tri, seed=1, max_wavefronts=bounces, rng_mode=mode, device_bvh=True, batch=2, flags=flags)
         assert len(pt.bvh_tree.nodes) == int(g["n_nodes"])
         pt.render_sample()

@@ -166,3 +166,34 @@ def test_adversarial_rays_model_equals_reference(orc, scene):
     assert _mismatches(O, o, n, extent, 3)[0] == 0
     assert _mismatches(O, o, n, extent, 1)[0] > 20
     o.close()
+
+
+@pytest.mark.parametrize("n_tri,scale", [(1200, 12.0), (30000, 3.0)])
+def test_grazing_rays_on_a_mesh_model_equals_reference(orc, n_tri, scale):
+    """Triangles (a build extension): the primitive test's rounding slack has no closed bound like the sphere's -- it grows like
+    1 / (cos(angle between ray and normal) * sin(angle between the edges)) -- so the free walks' equivalence with the reference's walk is
+    argued from the leaf-box verdict plus the margin and checked here where the slack is largest: rays within 1e-7 .. 1e-2 rad of
+    a triangle's plane that pass its edges at +-1e-7 .. 1e-3 edge lengths (helpers.grazing_rays_mesh), through the CPU models of both
+    free walks (mode 3: one verdict after the walk; mode 2: refill_kernel's verdict per changed leaf) against the reference's walk."""
+    import types
+    from helpers import grazing_rays_mesh
+    O = orc
+    W = types.SimpleNamespace(RAY=O.RAY)
+    w, h = 256, 128
+    tris, mt = O.scene_random_mesh(n_tri, 1)
+    tris["e1"] *= np.float32(scale); tris["e2"] *= np.float32(scale)
+    tris, nodes = O.build_bvh_triangles(tris, 32)
+    cam, ip, vw = O.mesh_camera(w, h)
+    o = O.Oracle(w, h, np.zeros(1, O.SPHERE), mt, nodes, cam, ip, vw, triangles=tris)
+    rays = grazing_rays_mesh(W, tris, w * h)
+    n = len(rays)
+    assert n > 10000
+    o.set_frame(1, 0); o.write_rays(rays.view(O.RAY)); o.set_counters([0, 0, n])
+    extent = _extent(O, nodes, cam, None)
+    for mode in (3, 2):
+        cnt, rows = _mismatches(O, o, n, extent, mode)
+        assert cnt == 0, f"mode {mode}: {cnt} grazing rays differ, first {rows[:4]}"
+    o.extend(*O.workgroup_size_64(n))
+    c = o.counters()
+    assert int(c[1]) > n // 20 and int(c[0]) > n // 20  # the set both hits and misses
+    o.close()

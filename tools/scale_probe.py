@@ -20,13 +20,33 @@ ap.add_argument("--all-ranks", action="store_true")
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--scene", choices=["shirley", "mesh"], default="shirley")
+ap.add_argument("--batch", type=int, default=0, help="samples in flight per launch (0 = --spp, at most 128): BASELINE config 3 is --spp 256 --batch 128")
+ap.add_argument("--flags", type=int, default=0, help="WFPT_FLAG_* bits for every context (e.g. 128 = no class binning)")
 args = ap.parse_args()
 w, h = 1920, 1080
+batch = args.batch or min(args.spp, 128)
+
+
+def header():
+    """Provenance of what is printed: command, commit the library was built from, device, date (profiles/ files carry it)."""
+    import datetime
+    from wavefront_path_tracer_amd import _build
+    info = _build.build_info()
+    try:
+        import torch
+        dev = torch.cuda.get_device_name(0)
+    except Exception:
+        dev = "?"
+    print(f"# command: python tools/scale_probe.py {' '.join(sys.argv[1:])}   commit {info.get('git_head')} (dirty at build: {info.get('git_dirty')}, "
+          f"sources match build: {info.get('sources_match_build')})   device: {dev}   {datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%M:%SZ')}", flush=True)
+
+
+header()
 
 
 def run(world, rank):
     make = (lambda *a, **k: W.mesh_path_tracer(a[0], a[1], 1000000, **k)) if args.scene == "mesh" else W.shirley_path_tracer
-    pt = make(w, h, max_wavefronts=8, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=args.spp)
+    pt = make(w, h, max_wavefronts=8, rng_mode=W.RNG_PIXEL, tile_rank=rank, tile_world=world, batch=batch, flags=args.flags)
     for _ in range(2):
         pt.reset_progress()
         pt.render(args.spp)

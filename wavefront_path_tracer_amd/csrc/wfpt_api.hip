@@ -82,6 +82,11 @@ struct wfpt_ctx {
     uint8_t *hit_flags = nullptr;
     uint4 *rank_table = nullptr;
     uint32_t bounce_binned_blocks_per_cu = 1;
+    // two chains: the fused loop's batch runs as two halves on two streams, so that the tail of one half's launch
+    // (a handful of long rays) overlaps with the bulk of the other's
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t spill_words = 0; // words of one chain's stack-spill area (HBM-resident scenes)
     // multi-GPU gather of the band-sharded frame (RCCL over xGMI)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -257,18 +262,20 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.scene = c->scene;
     return a;
 }
-ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce, uint32_t nb = 1, int fused_parity = -1) {
+// `first`: the chain's first sample (two chains: the per-sample arrays of a chain start `first` slices in)
+ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce, uint32_t nb = 1, int fused_parity = -1, uint32_t first = 0) {
     ScanArgs a{};
     a.batch = batch_of(c, nb);
-    a.chunk_hits = c->chunk_hits; a.chunk_miss = c->chunk_miss;
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max;
+    a.chunk_hits = c->chunk_hits + co; a.chunk_miss = c->chunk_miss + co;
     if (fused_parity >= 0) { // counts written by the fused bounce kernel of this wavefront
-        a.chunk_hits = c->f_chunk_hits[fused_parity];
-        a.chunk_miss = c->f_chunk_miss[fused_parity];
-        a.first_seg = c->first_seg;
+        a.chunk_hits = c->f_chunk_hits[fused_parity] + co;
+        a.chunk_miss = c->f_chunk_miss[fused_parity] + co;
+        a.first_seg = c->first_seg + co;
     }
-    a.chunk_hit_base = c->chunk_hit_base; a.chunk_miss_base = c->chunk_miss_base;
-    a.ctl = c->ctl;
-    a.n_in = n_in;
+    a.chunk_hit_base = c->chunk_hit_base + co; a.chunk_miss_base = c->chunk_miss_base + co;
+    a.ctl = c->ctl + first;
+    a.n_in = n_in + static_cast<size_t>(first) * a.batch.ctl_stride;
     a.limit = std::min(limit, c->capacity);
     a.fused = fused ? 1u : 0u;
     a.miss_floor = c->p.miss_floor;
@@ -326,30 +333,35 @@ AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping,
     return a;
 }
 
-BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb) {
+constexpr uint32_t kPlanWords = kMaxBatch * (kBinClasses + 2) + 8; // work-item plan of the class-binned loop, one per chain
+BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb, uint32_t first = 0) {
     BounceArgs a{};
     a.batch = batch_of(c, nb);
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
     a.stamps = c->d_stamps;
-    a.rec_in = c->rec_mem[in_parity];
-    a.rec_out = c->rec_mem[out_parity];
-    a.in_hits = c->f_chunk_hits[in_parity];
-    a.in_miss = c->f_chunk_miss[in_parity];
-    a.in_hit_base = c->chunk_hit_base;
-    a.in_first_seg = c->first_seg;
-    a.out_hits = c->f_chunk_hits[out_parity];
-    a.out_miss = c->f_chunk_miss[out_parity];
-    a.mq_in = c->f_mq[in_parity];
-    a.mq_out = c->f_mq[out_parity];
-    a.plan = c->plan;
-    a.plan_seg_off = nb * kBinClasses + 1u;
-    a.plan_miss_off = a.plan_seg_off + nb + 1u;
-    a.cls_table = c->cls_table;
-    a.first_seg_cls = c->first_seg_cls;
-    a.out_cls = c->f_cls[out_parity];
-    a.rank_in = c->rank_table;
-    a.flag_out = c->hit_flags;
-    a.image = c->image;
-    a.ctl = c->ctl;
+    a.rec_in = c->rec_mem[in_parity] + 2 * qo;
+    a.rec_out = c->rec_mem[out_parity] + 2 * qo;
+    a.in_hits = c->f_chunk_hits[in_parity] + co;
+    a.in_miss = c->f_chunk_miss[in_parity] + co;
+    a.in_hit_base = c->chunk_hit_base + co;
+    a.in_first_seg = c->first_seg + co;
+    a.out_hits = c->f_chunk_hits[out_parity] + co;
+    a.out_miss = c->f_chunk_miss[out_parity] + co;
+    a.mq_in = c->f_mq[in_parity]; a.mq_in.base += qo;
+    a.mq_out = c->f_mq[out_parity]; a.mq_out.base += qo;
+    if (c->bin_capable) {
+        constexpr size_t kWords = ClsPack<kBinClasses>::kWords;
+        a.plan = c->plan + (first ? kPlanWords : 0u);
+        a.plan_seg_off = nb * kBinClasses + 1u;
+        a.plan_miss_off = a.plan_seg_off + nb + 1u;
+        a.cls_table = c->cls_table + co * kBinClasses;
+        a.first_seg_cls = c->first_seg_cls + co * kBinClasses;
+        a.out_cls = c->f_cls[out_parity] + co * kWords;
+        a.rank_in = c->rank_table + qo / 64;
+        a.flag_out = c->hit_flags + qo;
+    }
+    a.image = c->image + static_cast<size_t>(first) * c->image_floats;
+    a.ctl = c->ctl + first;
     a.camera = c->camera;
     a.gx = c->tiles_x;
     a.gy = c->tiles_y_local;
@@ -358,18 +370,20 @@ BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb) 
     a.image_width = c->width;
     a.tile = c->tile;
     a.scene = c->scene;
+    if (first && a.scene.stack_spill) a.scene.stack_spill += c->spill_words;
     return a;
 }
-RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb) {
+RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb, uint32_t first = 0) {
     RefillArgs a{};
     a.batch = batch_of(c, nb);
-    a.rec_in = c->rec_mem[in_parity];
-    a.dense_out = c->rec_dense;
-    a.in_hits = c->f_chunk_hits[in_parity];
-    a.in_hit_base = c->chunk_hit_base;
-    a.in_first_seg = c->first_seg;
-    a.image = c->image;
-    a.ctl = c->ctl;
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
+    a.rec_in = c->rec_mem[in_parity] + 2 * qo;
+    a.dense_out = c->rec_dense + 2 * qo;
+    a.in_hits = c->f_chunk_hits[in_parity] + co;
+    a.in_hit_base = c->chunk_hit_base + co;
+    a.in_first_seg = c->first_seg + co;
+    a.image = c->image + static_cast<size_t>(first) * c->image_floats;
+    a.ctl = c->ctl + first;
     a.camera = c->camera;
     a.gx = c->tiles_x;
     a.gy = c->tiles_y_local;
@@ -378,49 +392,58 @@ RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb) {
     a.image_width = c->width;
     a.tile = c->tile;
     a.scene = c->scene;
+    if (first && a.scene.stack_spill) a.scene.stack_spill += c->spill_words; // the second chain's launches run beside the first's: a spill area of their own
     return a;
 }
-CompactArgs compact_args(wfpt_ctx *c, int out_parity, uint32_t nb) {
+CompactArgs compact_args(wfpt_ctx *c, int out_parity, uint32_t nb, uint32_t first = 0) {
     CompactArgs a{};
     a.batch = batch_of(c, nb);
-    a.dense_in = c->rec_dense;
-    a.rec_out = c->rec_mem[out_parity];
-    a.mq_out = c->f_mq[out_parity];
-    a.out_hits = c->f_chunk_hits[out_parity];
-    a.out_miss = c->f_chunk_miss[out_parity];
-    a.ctl = c->ctl;
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
+    a.dense_in = c->rec_dense + 2 * qo;
+    a.rec_out = c->rec_mem[out_parity] + 2 * qo;
+    a.mq_out = c->f_mq[out_parity]; a.mq_out.base += qo;
+    a.out_hits = c->f_chunk_hits[out_parity] + co;
+    a.out_miss = c->f_chunk_miss[out_parity] + co;
+    a.ctl = c->ctl + first;
     a.capacity = c->capacity;
     return a;
 }
-MissArgs fused_miss_args(wfpt_ctx *c, int parity, uint32_t nb) { // miss_kernel over the fused loop's miss queue of one wavefront
+MissArgs fused_miss_args(wfpt_ctx *c, int parity, uint32_t nb, uint32_t first = 0) { // miss_kernel over the fused loop's miss queue of one wavefront
     MissArgs a = miss_args(c, 0, &c->ctl->miss_n, c->capacity, nb);
-    a.mq = c->f_mq[parity];
-    a.chunk_miss = c->f_chunk_miss[parity];
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
+    a.mq = c->f_mq[parity]; a.mq.base += qo;
+    a.chunk_miss = c->f_chunk_miss[parity] + co;
+    a.chunk_miss_base = c->chunk_miss_base + co;
+    a.image = c->image + static_cast<size_t>(first) * c->image_floats;
+    a.ctl = c->ctl + first;
+    a.n_miss = &c->ctl[first].miss_n;
     return a;
 }
-ScanBinnedArgs scan_binned_args(wfpt_ctx *c, uint32_t bounce, uint32_t nb, int parity) {
+ScanBinnedArgs scan_binned_args(wfpt_ctx *c, uint32_t bounce, uint32_t nb, int parity, uint32_t first = 0) {
     ScanBinnedArgs a{};
     a.batch = batch_of(c, nb);
-    a.chunk_hits = c->f_chunk_hits[parity];
-    a.chunk_miss = c->f_chunk_miss[parity];
-    a.chunk_cls = c->f_cls[parity];
-    a.cls_table = c->cls_table;
-    a.first_seg_cls = c->first_seg_cls;
+    constexpr size_t kWords = ClsPack<kBinClasses>::kWords;
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
+    a.chunk_hits = c->f_chunk_hits[parity] + co;
+    a.chunk_miss = c->f_chunk_miss[parity] + co;
+    a.chunk_cls = c->f_cls[parity] + co * kWords;
+    a.cls_table = c->cls_table + co * kBinClasses;
+    a.first_seg_cls = c->first_seg_cls + co * kBinClasses;
     const bool keyed_by_order = c->p.rng_mode != WFPT_RNG_PIXEL;
-    a.flags = keyed_by_order ? c->hit_flags : nullptr;
-    a.rank = keyed_by_order ? c->rank_table : nullptr;
-    a.ctl = c->ctl;
-    a.n_in = &c->ctl->n_in;
+    a.flags = keyed_by_order ? c->hit_flags + qo : nullptr;
+    a.rank = keyed_by_order ? c->rank_table + qo / 64 : nullptr;
+    a.ctl = c->ctl + first;
+    a.n_in = &c->ctl[first].n_in;
     a.limit = c->capacity;
     a.miss_floor = c->p.miss_floor;
     a.bounce = bounce;
     return a;
 }
-PlanArgs plan_args(wfpt_ctx *c, uint32_t nb, bool last) {
+PlanArgs plan_args(wfpt_ctx *c, uint32_t nb, bool last, uint32_t first = 0) {
     PlanArgs a{};
     a.batch = batch_of(c, nb);
-    a.ctl = c->ctl;
-    a.plan = c->plan;
+    a.ctl = c->ctl + first;
+    a.plan = c->plan + (first ? kPlanWords : 0u);
     a.plan_seg_off = nb * kBinClasses + 1u;
     a.plan_miss_off = a.plan_seg_off + nb + 1u;
     a.last = last ? 1u : 0u;
@@ -438,8 +461,69 @@ uint32_t bounce_grid(const wfpt_ctx *c, uint32_t n) {
     return static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->bounce_blocks_per_cu));
 }
 
-// One fused sample on the stream (pt:291-368). `ev`: optional (stage, start, stop) event recorder.
+constexpr uint32_t kChainMinSamples = 2; // a batch of at least twice this many samples runs as two chains
+// One batch of fused samples on the stream (pt:291-368). `ev`: optional (stage, start, stop) event recorder.
 struct EventRec { int stage; hipEvent_t start, stop; };
+
+// The wavefront chain of the samples [first, first + nb) of a batch on `st`, up to (not including) accumulate. Returns false if this
+// context's loop is not one of the fused ones (the stage kernels one by one: enqueue_batch).
+template <typename Timed>
+int enqueue_fused_chain(wfpt_ctx *c, Timed &timed, uint32_t nb, uint32_t first, hipStream_t st) {
+    if (c->fused && c->rec_dense && !c->scene.exact) {
+        // HBM-resident scene: traversal with dynamic lane refill. Per wavefront: (miss_kernel of the previous one) |
+        // refill-trace into dense per-ray records | compact into the queues | scan; then shade+miss of the last one.
+        const uint32_t grid = c->cus * c->bounce_blocks_per_cu;
+        if (WFPT_PRESHADE) // generate_rays at full waves into the dense array, then the traversal refills from it
+            WFPT_HIP(c, timed(WFPT_STAGE_GENERATE_RAYS, [&] { return launch_generate_dense(refill_args(c, 1, nb, first), st); }));
+        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_refill(refill_args(c, 1, nb, first), kBounceFirst, grid, st, WFPT_PRESHADE != 0); }));
+        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+            const int par = static_cast<int>(b & 1u);
+            WFPT_HIP(c, timed(WFPT_STAGE_COMPACT, [&] { return launch_compact(compact_args(c, par, nb, first), c->n_chunks_max, st); }));
+            WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
+                              [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par, first), st); }));
+            if (b + 1 < c->p.max_wavefronts) {
+                WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] { return launch_miss(fused_miss_args(c, par, nb, first), consumer_grid(c, nb), st); }));
+                if (WFPT_PRESHADE) // shade at full waves into the dense array, then the traversal refills from it
+                    WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] { return launch_shade_rays(refill_args(c, par, nb, first), c->n_chunks_max, st); }));
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_refill(refill_args(c, par, nb, first), kBounceMiddle, grid, st, WFPT_PRESHADE != 0); }));
+            } else {
+                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb, first), kBounceLast, bounce_grid(c, nb), st); }));
+            }
+        }
+        return WFPT_OK;
+    }
+    if (use_binned(c)) {
+        // the same chain with the hit queue binned by cost class: generate+extend | scan, plan | (shade+extend+miss | scan, plan) x (max - 1) | shade+miss
+        const uint64_t items = (static_cast<uint64_t>(c->n_chunks_max) * 5u / 4u + 1u) * nb;
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->bounce_binned_blocks_per_cu));
+        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_bounce_binned(bounce_args(c, 1, 0, nb, first), kBounceFirst, grid, st); }));
+        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+            const int par = static_cast<int>(b & 1u);
+            const bool last = b + 1 >= c->p.max_wavefronts;
+            WFPT_HIP(c, timed(WFPT_STAGE_SCAN, [&] {
+                         hipError_t e = launch_scan_binned(scan_binned_args(c, b, nb, par, first), st);
+                         return e != hipSuccess ? e : launch_plan(plan_args(c, nb, last, first), st);
+                     }));
+            WFPT_HIP(c, timed(last ? WFPT_STAGE_BOUNCE_LAST : WFPT_STAGE_BOUNCE,
+                              [&] { return launch_bounce_binned(bounce_args(c, par, par ^ 1, nb, first), last ? kBounceLast : kBounceMiddle, grid, st); }));
+        }
+        return WFPT_OK;
+    }
+    // generate+extend | scan | (shade+extend+miss | scan) x (max_wavefronts - 1) | shade+miss
+    const uint32_t grid = bounce_grid(c, nb);
+    WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_bounce(bounce_args(c, 1, 0, nb, first), kBounceFirst, grid, st); }));
+    for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
+        const int par = static_cast<int>(b & 1u);
+        WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
+                          [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par, first), st); }));
+        if (b + 1 < c->p.max_wavefronts)
+            WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb, first), kBounceMiddle, grid, st); }));
+        else
+            WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb, first), kBounceLast, grid, st); }));
+    }
+    return WFPT_OK;
+}
+
 int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     size_t next_event = 0;
     auto timed = [&](int stage, auto &&launch) -> hipError_t {
@@ -464,65 +548,22 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     };
     c->cur = 0;
     const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
-    if (c->fused && c->rec_dense && !c->scene.exact) {
-        // HBM-resident scene: traversal with dynamic lane refill. Per wavefront: (miss_kernel of the previous one) |
-        // refill-trace into dense per-ray records | compact into the queues | scan; then shade+miss of the last one.
-        const uint32_t grid = c->cus * c->bounce_blocks_per_cu;
-        if (WFPT_PRESHADE) // generate_rays at full waves into the dense array, then the traversal refills from it
-            WFPT_HIP(c, timed(WFPT_STAGE_GENERATE_RAYS, [&] { return launch_generate_dense(refill_args(c, 1, nb), c->stream); }));
-        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_refill(refill_args(c, 1, nb), kBounceFirst, grid, c->stream, WFPT_PRESHADE != 0); }));
-        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
-            const int par = static_cast<int>(b & 1u);
-            WFPT_HIP(c, timed(WFPT_STAGE_COMPACT, [&] { return launch_compact(compact_args(c, par, nb), c->n_chunks_max, c->stream); }));
-            WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
-                              [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par), c->stream); }));
-            if (b + 1 < c->p.max_wavefronts) {
-                WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] { return launch_miss(fused_miss_args(c, par, nb), consumer_grid(c, nb), c->stream); }));
-                if (WFPT_PRESHADE) // shade at full waves into the dense array, then the traversal refills from it
-                    WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] { return launch_shade_rays(refill_args(c, par, nb), c->n_chunks_max, c->stream); }));
-                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_refill(refill_args(c, par, nb), kBounceMiddle, grid, c->stream, WFPT_PRESHADE != 0); }));
-            } else {
-                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceLast, bounce_grid(c, nb), c->stream); }));
-            }
-        }
-        WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
-                     return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
-                 }));
-        return WFPT_OK;
-    }
-    if (use_binned(c)) {
-        // the same chain with the hit queue binned by cost class: generate+extend | scan, plan | (shade+extend+miss | scan, plan) x (max - 1) | shade+miss | accumulate
-        const uint64_t items = (static_cast<uint64_t>(c->n_chunks_max) * 5u / 4u + 1u) * nb;
-        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->bounce_binned_blocks_per_cu));
-        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_bounce_binned(bounce_args(c, 1, 0, nb), kBounceFirst, grid, c->stream); }));
-        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
-            const int par = static_cast<int>(b & 1u);
-            const bool last = b + 1 >= c->p.max_wavefronts;
-            WFPT_HIP(c, timed(WFPT_STAGE_SCAN, [&] {
-                         hipError_t e = launch_scan_binned(scan_binned_args(c, b, nb, par), c->stream);
-                         return e != hipSuccess ? e : launch_plan(plan_args(c, nb, last), c->stream);
-                     }));
-            WFPT_HIP(c, timed(last ? WFPT_STAGE_BOUNCE_LAST : WFPT_STAGE_BOUNCE,
-                              [&] { return launch_bounce_binned(bounce_args(c, par, par ^ 1, nb), last ? kBounceLast : kBounceMiddle, grid, c->stream); }));
-        }
-        WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
-                     return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
-                 }));
-        return WFPT_OK;
-    }
     if (c->fused) {
-        // generate+extend | scan | (shade+extend+miss | scan) x (max_wavefronts - 1) | shade+miss | accumulate
-        const uint32_t grid = bounce_grid(c, nb);
-        WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_FIRST, [&] { return launch_bounce(bounce_args(c, 1, 0, nb), kBounceFirst, grid, c->stream); }));
-        for (uint32_t b = 0; b < c->p.max_wavefronts; ++b) {
-            const int par = static_cast<int>(b & 1u);
-            WFPT_HIP(c, timed(WFPT_STAGE_SCAN,
-                              [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb, par), c->stream); }));
-            if (b + 1 < c->p.max_wavefronts)
-                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceMiddle, grid, c->stream); }));
-            else
-                WFPT_HIP(c, timed(WFPT_STAGE_BOUNCE_LAST, [&] { return launch_bounce(bounce_args(c, par, par ^ 1, nb), kBounceLast, grid, c->stream); }));
+        // Two chains (WFPT_FLAG_TWO_CHAINS, an experiment kept for measurement): a launch of the fused loop ends on its longest rays -- a
+        // tail in which most of the chip idles. The batch's samples are independent, so its two halves can run as two chains on two
+        // streams (two branches of the captured graph): while one half's launch drains, the other half's fills the chip. Measured: slower
+        // at every slab size (the halves' launches pay the per-launch costs twice and do not overlap the way the picture suggests).
+        // The event-timed pass (wfpt_render_timed) always runs one chain.
+        const uint32_t n1 = (!ev && c->stream2 && nb >= 2u * kChainMinSamples && (c->p.flags & WFPT_FLAG_TWO_CHAINS)) ? nb / 2u : 0u;
+        if (n1) {
+            WFPT_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            WFPT_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            WFPT_HIP(c, launch_chain_head(c->ctl, nb - n1, c->stream2)); // frame uniform and ticket of the second chain's first Control block
+            if (int r = enqueue_fused_chain(c, timed, n1, nb - n1, c->stream2); r != WFPT_OK) return r;
+            WFPT_HIP(c, hipEventRecord(c->ev_join, c->stream2));
         }
+        if (int r = enqueue_fused_chain(c, timed, nb - n1, 0, c->stream); r != WFPT_OK) return r;
+        if (n1) WFPT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
                      return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
                  }));
@@ -940,7 +981,8 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
         const uint32_t need = 3u * (c->depth4 + 1u);
         const uint32_t spill_entries = need > kStack4Lds ? need - kStack4Lds : 1u;
         c->scene.spill_stride = c->cus * std::max(c->blocks_per_cu, c->bounce_blocks_per_cu) * static_cast<uint32_t>(kExtendThreads);
-        WFPT_HIP(c, dmalloc(&c->d_stack_spill, static_cast<size_t>(spill_entries) * c->scene.spill_stride));
+        c->spill_words = static_cast<size_t>(spill_entries) * c->scene.spill_stride;
+        WFPT_HIP(c, dmalloc(&c->d_stack_spill, 2 * c->spill_words)); // one area per chain (enqueue_batch)
         c->scene.stack_spill = c->d_stack_spill;
     }
     return WFPT_OK;
@@ -1063,6 +1105,9 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
 
     CREATE_HIP(hipSetDevice(c->device));
     CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    CREATE_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CREATE_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     set_viewport(c, params->width, params->height);
     c->pixel_capacity = std::max(c->n_pixels, c->tile.world <= 1 ? params->max_pixels : 0u);
     // ray slots: whole tiles (partial tiles carry padding lanes), rounded up to whole segments
@@ -1076,8 +1121,12 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     // pixel index, so both must stay below 2^23 (3840x2160 does); larger contexts keep the thread-ordered queue.
     // (default in the pixel-keyed RNG mode, where the order of the queue is free; on request in the dispatch-keyed mode, where carrying the
     // reference's order through the binning costs what the binning gains: include/wfpt.h, WFPT_FLAG_BINNING)
+    // A small slab gains nothing: every class of every sample ends on a partly filled work item, and the late wavefronts of 1/4 or 1/8
+    // of a 1920x1080 frame are a handful of work items per sample (measured per rank of N = 1 / 2 / 4 / 8, 64 samples in flight:
+    // 18.53 / 9.77 / 5.28 / 3.08 ms binned against 19.08 / 9.85 / 5.14 / 2.90 in thread order), so the default asks for 3/4 Mpixel.
+    const bool auto_on = params->rng_mode == WFPT_RNG_PIXEL && (params->flags & WFPT_FLAG_NO_BINNING) == 0 && c->n_pixels >= (3u << 18);
     const bool want_binning = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE | WFPT_FLAG_NO_LDS_SCENE)) == 0 &&
-                              (params->rng_mode == WFPT_RNG_PIXEL ? (params->flags & WFPT_FLAG_NO_BINNING) == 0 : (params->flags & WFPT_FLAG_BINNING) != 0);
+                              (auto_on || (params->flags & WFPT_FLAG_BINNING) != 0);
     if (want_binning && cap + kBinClasses * kChunk <= (1ull << 23) && c->pixel_capacity <= (1u << 23) &&
         static_cast<uint64_t>(params->width) * params->height <= (1ull << 23)) {
         cap += kBinClasses * kChunk;
@@ -1154,8 +1203,8 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
             CREATE_HIP(hipMemsetAsync(c->cls_table, 0, sizeof(uint2) * counts * kBinClasses, c->stream));
             CREATE_HIP(dmalloc(&c->first_seg_cls, counts * kBinClasses));
             CREATE_HIP(hipMemsetAsync(c->first_seg_cls, 0, sizeof(uint32_t) * counts * kBinClasses, c->stream));
-            CREATE_HIP(dmalloc(&c->plan, kMaxBatch * (kBinClasses + 2) + 8));
-            CREATE_HIP(hipMemsetAsync(c->plan, 0, sizeof(uint32_t) * (kMaxBatch * (kBinClasses + 2) + 8), c->stream));
+            CREATE_HIP(dmalloc(&c->plan, 2 * kPlanWords));
+            CREATE_HIP(hipMemsetAsync(c->plan, 0, sizeof(uint32_t) * 2 * kPlanWords, c->stream));
             CREATE_HIP(dmalloc(&c->hit_flags, slots));
             CREATE_HIP(hipMemsetAsync(c->hit_flags, 0, slots, c->stream));
             CREATE_HIP(dmalloc(&c->rank_table, slots / 64));
@@ -1296,6 +1345,9 @@ void wfpt_destroy(wfpt_ctx *c) {
                     c->camera, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -402,6 +402,8 @@ hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s);
 hipError_t launch_set_frame(Control *ctl, const wfpt_frame_buffer &f, hipStream_t s); // ctl->frame = f, ordered on the stream
+// second chain of a batch: ctl[first] gets the frame uniform of sample `first` (ctl[0]'s, frame + first) and a fresh ticket
+hipError_t launch_chain_head(Control *ctl, uint32_t first, hipStream_t s);
 // frame band (j * world + rank) <- slab band j for the first n_valid floats of a slab: the root of the multi-GPU gather
 hipError_t launch_band_scatter(float *frame, const float *slab, size_t n_valid, size_t band_floats, uint32_t world, uint32_t rank, hipStream_t s);
 // AoS <-> SoA converters for the read-back / injection paths

@@ -2548,6 +2548,13 @@ __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
 // the frame uniform of the next sample (pt:296-297), written on the stream: no host synchronisation between frames
 __global__ void set_frame_kernel(Control *ctl, wfpt_frame_buffer f) { ctl->frame = f; }
 
+__global__ void chain_head_kernel(Control *ctl, uint32_t first) {
+    wfpt_frame_buffer f = ctl[0].frame;
+    f.frame += first;
+    ctl[first].frame = f;
+    ctl[first].ticket = 0;
+}
+
 __global__ void fill_kernel(float *p, float v, size_t n) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -2829,6 +2836,11 @@ hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t
 
 hipError_t launch_set_frame(Control *ctl, const wfpt_frame_buffer &f, hipStream_t s) {
     hipLaunchKernelGGL(set_frame_kernel, dim3(1), dim3(1), 0, s, ctl, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_head(Control *ctl, uint32_t first, hipStream_t s) {
+    hipLaunchKernelGGL(chain_head_kernel, dim3(1), dim3(1), 0, s, ctl, first);
     return hipGetLastError();
 }
 
