@@ -221,6 +221,9 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
 #ifndef WFPT_VISIT4_PK
 #define WFPT_VISIT4_PK 0 // 1: visit4's plane distances two children at a time with v_pk_fma_f32
 #endif
+#ifndef WFPT_VISIT4_PARTIAL_SORT
+#define WFPT_VISIT4_PARTIAL_SORT 0 // 1: visit4 brings only the nearest child to the front (measured: profiles/r04_rejected_experiments.txt)
+#endif
 #ifndef WFPT_LEAF_LANES
 #define WFPT_LEAF_LANES 8 // refill_kernel: lanes that have to wait at a leaf before the wave runs the leaf code
 #endif
@@ -827,8 +830,13 @@ __device__ __forceinline__ Visit4 visit4(const float4 a, const float4 b, const f
     // (an absent child has an inverted box, qlo = 255 > qhi = 0 on every axis, so it is not entered; should rounding ever make its
     // two plane distances meet, its word is a leaf of no primitives: nothing to guard here)
     v.t0 = t[0]; v.t1 = t[1]; v.t2 = t[2]; v.t3 = t[3];
+#if WFPT_VISIT4_PARTIAL_SORT
+    // only the nearest child is brought to the front (three compare-exchanges instead of five); the others are pushed in slot order
+    order2(v.t0, v.w0, v.t1, v.w1); order2(v.t2, v.w2, v.t3, v.w3); order2(v.t0, v.w0, v.t2, v.w2);
+#else
     order2(v.t0, v.w0, v.t1, v.w1); order2(v.t2, v.w2, v.t3, v.w3); order2(v.t0, v.w0, v.t2, v.w2); order2(v.t1, v.w1, v.t3, v.w3);
     order2(v.t1, v.w1, v.t2, v.w2);
+#endif
     return v;
 }
 // the node's four 16-byte quarters: from the LDS copy of the top of the tree (tile, nodes [0, tile_n)) or from global memory
