@@ -5,6 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa
 import wavefront_path_tracer_amd as W
+import datetime
+from wavefront_path_tracer_amd import _build
+info = _build.build_info()
+print(f"# command: WFPT_LIB={os.environ.get('WFPT_LIB', '')} python tools/stamps_probe.py {' '.join(sys.argv[1:])}   commit {info.get('git_head')} "
+      f"(dirty at build: {info.get('git_dirty')}; the -DWFPT_STAMPS=1 diagnostic build of the same sources)   device: {torch.cuda.get_device_name(0)}   "
+      f"{datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%M:%SZ')}")
 flags = W.FLAG_EXACT_TRAVERSAL if "--exact" in sys.argv else 0
 pt = W.shirley_path_tracer(1920, 1080, seed=1, max_wavefronts=8, batch=64, flags=flags)
 pt.render(64)
