@@ -6,7 +6,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 out=gpurun_out
-args="--steps 2 --warmup 1 --no-cpu-baseline $*"   # 3 + 2 frames of 64 samples per pixel, all 64 in flight
+args="--steps 2 --warmup 1 --no-cpu-baseline --no-pixel-anchor $*"   # 3 + 2 frames of 64 samples per pixel, all 64 in flight
 run() { # name, rocprof options...
   name=$1; shift
   rm -rf $out/prof_${tag}_$name

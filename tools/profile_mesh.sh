@@ -3,7 +3,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 out=gpurun_out
-args="--scene mesh --steps 1 --warmup 1 --no-cpu-baseline $*"   # frames of 64 samples per pixel, all 64 in flight
+args="--scene mesh --steps 1 --warmup 1 --no-cpu-baseline --no-pixel-anchor $*"   # frames of 64 samples per pixel, all 64 in flight
 run() { name=$1; shift
   rm -rf $out/prof_${tag}_$name
   timeout -k 10 240 rocprofv3 "$@" --output-format csv -d $out/prof_${tag}_$name -- python3 bench.py $args > $out/prof_${tag}_$name.json 2> $out/prof_${tag}_$name.err \
