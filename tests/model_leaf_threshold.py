@@ -21,7 +21,7 @@ from tests.helpers import inputs_for, make_oracle  # noqa: E402
 import tests.model_schedule as MS  # noqa: E402
 from tests.model_schedule import pad, rounds_of  # noqa: E402
 
-if len(sys.argv) > 2:
+if __name__ == "__main__" and len(sys.argv) > 2:
     MS.C_VISIT, MS.C_LEAF = float(sys.argv[1]), float(sys.argv[2])
 C_VISIT, C_LEAF, wave_cost = MS.C_VISIT, MS.C_LEAF, MS.wave_cost
 

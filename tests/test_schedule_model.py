@@ -61,3 +61,35 @@ def test_schedule_model_runs(orc, monkeypatch, capsys):
     segs[0, 0] = 30
     assert m.model_base(segs, nl) == m.lane_work(segs, nl)[0]
     assert m.model_sort(np.concatenate([segs, segs]), np.concatenate([nl, nl]), np.arange(128, dtype=np.float64), 128) == 2 * m.model_base(segs, nl)
+
+
+def test_binning_model_scores(orc):
+    """tests/model_binning.py (global binning of the hit queue by key) and tests/model_leaf_threshold.py (if-if schedule with a leaf-lane
+    threshold): the scoring functions on hand-made waves."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tests", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    mb = load("model_binning")
+    # two kinds of rays, cheap and dear, alternating: in hit order every wave pays for the dear ones, binned by kind half of them do
+    n = 1024
+    segs = np.zeros((n, 16), np.int32)
+    segs[:, 0] = np.where(np.arange(n) % 2 == 0, 2, 20)
+    nl = np.ones(n, np.int32)
+    mat = (np.arange(n) % 2).astype(np.int64)
+    base = mb.score(segs, nl, mat)
+    binned = mb.score(segs, nl, mat, mb.binned_order(np.arange(n) % 2))
+    assert binned["rounds"] < 0.6 * base["rounds"] and binned["trace"] < 0.6 * base["trace"]
+    assert binned["shade"] < base["shade"]  # a wave of one material runs one branch
+    assert mb.score(segs, nl, mat, mb.binned_order(np.zeros(n, np.int64)))["trace"] == base["trace"]  # one class: the hit order
+    ml = load("model_leaf_threshold")
+    # 64 identical lanes: every schedule costs the lane's own work
+    s = np.tile(np.array([[3, 2] + [0] * 14], np.int32), (64, 1))
+    l = np.full(64, 2, np.int32)
+    cost, it_v, it_l = ml.sim_ifif(s, l, 8)
+    assert (it_v, it_l) == (5, 2) and cost == 5 * ml.C_VISIT + 2 * ml.C_LEAF

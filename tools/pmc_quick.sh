@@ -12,7 +12,7 @@ dur = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void wfpt::(anonymous namespace)::", "").replace("wfpt::(anonymous namespace)::", "")
+        k = r["Kernel_Name"].replace("void wfpt::(anonymous namespace)::", "").replace("wfpt::(anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"]); dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
