@@ -94,3 +94,20 @@ def test_binned_loop_in_band_shards(gpu, orc):
                            flags=W.FLAG_BINNING)  # (slabs this small keep the thread-ordered queue by default)
     assert_bit_equal(acc, want, "3 band shards, binned")
     o.close()
+
+
+@pytest.mark.parametrize("rng_mode", [0, 1])
+@pytest.mark.parametrize("bounces,miss_floor", [(1, 128), (2, 128), (3, 10 ** 9), (8, 3000)])
+def test_binned_loop_short_chains_and_early_exits(gpu, orc, rng_mode, bounces, miss_floor):
+    """One and two wavefronts (no middle launch at all / exactly one), a miss floor that stops the loop right after the first extend
+    (path_tracer.rs:332: the hits are never shaded), and one that stops it in the middle of the chain for some samples of the batch."""
+    W = gpu
+    w, h, spp = 200, 120, 5
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, rng_mode=rng_mode, max_wavefronts=bounces, miss_floor=miss_floor)
+    want = o.render(spp)
+    pt = make_tracer(W, "shirley", w, h, rng_mode=rng_mode, max_wavefronts=bounces, miss_floor=miss_floor, flags=W.FLAG_BINNING, batch=3)
+    pt.render(spp)
+    assert np.array_equal(pt.bounce_table(), o.bounce_table())
+    assert_bit_equal(pt.accumulated(), want, f"{bounces} wavefronts, miss floor {miss_floor}, mode {rng_mode}")
+    assert np.array_equal(pt.totals(), o.totals())
+    pt.close(); o.close()
