@@ -234,7 +234,7 @@ def test_full_hd_as_eight_band_shards_against_golden(gpu):
 
 
 # ------------------------------------------------------------------ dynamic scenes
-@pytest.mark.parametrize("flags", [0, "UNFUSED"])
+@pytest.mark.parametrize("flags", [0, "UNFUSED", "BINNING"])  # BINNING: the class-binned loop (cost classes are re-derived by upload_scene)
 def test_update_scene_moves_fifty_spheres(gpu, orc, flags):
     """wfpt_update_scene: move 50 spheres of the live context's scene; the BVH is rebuilt on the device, the accumulation
     restarts at frame 1, and the image equals both a fresh context on the moved scene and the oracle."""
