@@ -381,6 +381,15 @@ float wfpt_kernel_timing_us(wfpt_ctx *ctx, int stage);
  * device: frame += 1, image <- 1, generate, up to max_wavefronts x (extend, shade, miss) with the
  * `misses < miss_floor` exit evaluated on the device, accumulate. No host synchronisation. Sizes that
  * are not multiples of 8 use true-size semantics: out-of-image lanes emit inactive rays. */
+/* Which loop wfpt_render enqueues for this context, as decided at wfpt_create / wfpt_update_scene from the flags, the RNG mode, the size
+ * of the slab and the scene (hosts and benchmarks label their figures with this instead of re-deriving the library's gates):
+ *   WFPT_LOOP_STAGES        the stage kernels one by one (WFPT_FLAG_UNFUSED / WFPT_FLAG_SPLIT_SHADE, or more than 65535 queue segments)
+ *   WFPT_LOOP_FUSED         one fused bounce launch per wavefront, hit queue in the reference's thread order (bounce_kernel)
+ *   WFPT_LOOP_FUSED_BINNED  the same with the hit queue binned by cost class (WFPT_RNG_PIXEL, scenes in LDS; bounce_binned_kernel)
+ *   WFPT_LOOP_REFILL        scenes beyond LDS: four-wide traversal with dynamic lane refill (refill_kernel)
+ * Returns the kind, or a negative status. */
+typedef enum wfpt_loop_kind { WFPT_LOOP_STAGES = 0, WFPT_LOOP_FUSED = 1, WFPT_LOOP_FUSED_BINNED = 2, WFPT_LOOP_REFILL = 3 } wfpt_loop_kind;
+int wfpt_loop_kind_of(const wfpt_ctx *ctx);
 int wfpt_render_sample(wfpt_ctx *ctx);
 int wfpt_render(wfpt_ctx *ctx, uint32_t n_samples);
 int wfpt_synchronize(wfpt_ctx *ctx);
@@ -417,6 +426,10 @@ int wfpt_copy_accumulated_to_device(wfpt_ctx *ctx, void *device_ptr, size_t n_by
 int wfpt_comm_unique_id(void *id128);
 int wfpt_comm_init(wfpt_ctx *ctx, const void *id128, int rank, int world);
 int wfpt_gather_accumulated(wfpt_ctx *ctx);
+/* The same gather bracketed by two events on the context's stream; blocks until it is done and returns its duration on this rank
+ * (BASELINE.md section 3's "gather time"). What the stream did before -- renders still in flight -- is waited for first, so the figure
+ * is the gather's own time when every rank calls it idle, after a barrier. */
+int wfpt_gather_accumulated_timed(wfpt_ctx *ctx, float *ms);
 int wfpt_read_gathered(wfpt_ctx *ctx, float *rgb, size_t n_floats);
 int wfpt_comm_destroy(wfpt_ctx *ctx); /* also done by wfpt_destroy */
 

@@ -67,6 +67,38 @@ def _limit_openmp():
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 
+def cpu_share():
+    """The CPUs this job may really use: the affinity mask and, where the job runs under one, the cgroup CPU quota (v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`). `granted` = min(quota, affinity) threads; without a quota the affinity mask is all there is
+    to go by (bench.py then times the CPU baseline at 16 threads AND at the whole mask)."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota, source = None, "no cgroup CPU quota found"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        source = f"/sys/fs/cgroup/cpu.max = '{q} {per}'"
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            source = f"cpu.cfs_quota_us / cpu.cfs_period_us = {q} / {per}"
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    granted = affinity if quota is None else max(1, min(affinity, int(quota + 0.999)))
+    return {"affinity": affinity, "host_cpus": os.cpu_count() or affinity, "quota_cores": quota, "quota_source": source, "granted": granted}
+
+
+def set_num_threads(n):
+    """OpenMP threads of the following oracle calls (the results do not depend on it)."""
+    lib().orc_set_num_threads(int(n))
+
+
 def lib(serial=False):
     key = "serial" if serial else "omp"
     if key in _libs:
@@ -144,6 +176,7 @@ def lib(serial=False):
     L.orc_trace_bvh.argtypes = [vp, vp, vp]
     L.orc_tonemap_rgb8.argtypes = [vp, u32, u32, vp]
     L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
     _libs[key] = L
     return L
 

@@ -1544,3 +1544,13 @@ int orc_num_threads(void) {
     return 1;
 #endif
 }
+
+/* threads of the following parallel regions (the CPU baseline is timed at the box's CPU share and, where that is not a quota, at every
+ * core of the affinity mask as well); results do not depend on the thread count (stable compactions, disjoint outputs) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -148,6 +148,7 @@ void     orc_traversal_profile(orc_ctx *, uint32_t n, uint64_t out[16]); /* diag
 /* display_shader.wgsl:50-52: sqrt(acc / n) -> 8-bit RGB */
 void     orc_tonemap_rgb8(const float *acc, uint32_t n_pixels, uint32_t n_samples, uint8_t *rgb);
 int      orc_num_threads(void);
+void     orc_set_num_threads(int n);
 
 /* model of the DEVICE's conservative traversal vs the reference's, over the ray queue (see wfpt_oracle.c) */
 void     orc_probe_normalize3(const float *in, float *out, size_t n); /* test probe */

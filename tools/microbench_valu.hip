@@ -24,7 +24,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2))); // a 128-bit VGPR tuple inline asm can name
 
 enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW,
-            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, PKFMA, FMAMIX, PERM, MINU, MULLO, MULHI, MAD64, DIVSCALE, DIVFMAS, DIVFIXUP, EXPF, LOGF, READLANE, WRITELANE, LSHLADD64, PKMUL, CVTFU, N_KINDS };
+            MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, PKFMA, FMAMIX, PERM, MINU, MULLO, MULHI, MAD64, DIVSCALE, DIVFMAS, DIVFIXUP, EXPF, LOGF, READLANE, WRITELANE, LSHLADD64, PKMUL, CVTFU, S_ADD, S_AND64, S_CSEL, S_LOADHIT, RFL_CHAIN, FMA_SALU16, FMA_SALU64, FMA_SAND32, MINMAX_SALU32, VISIT_MIX, N_KINDS };
 
 // one instruction of the class on register x (a, b: loop-invariant VGPRs; m: an SGPR pair holding a lane mask)
 #define I_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
@@ -68,10 +68,16 @@ enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, 
 #define I_PKMUL(k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[k]) : "v"(ya))
 #define I_CVTFU(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x))
 #define I_SALU() asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc")
+// scalar classes (round 5): independent instructions on 16 scalar registers
+#define I_SADD(k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ss[k]) : : "scc")
+#define I_SAND64(k) asm volatile("s_and_b64 %0, %0, %1" : "+s"(sm[k]) : "s"(m) : "scc")
+#define I_SCSEL(k) asm volatile("s_cselect_b32 %0, %0, %1" : "+s"(ss[k]) : "s"(sc))
+#define REPS16(OP) OP(0); OP(1); OP(2); OP(3); OP(4); OP(5); OP(6); OP(7); OP(8); OP(9); OP(10); OP(11); OP(12); OP(13); OP(14); OP(15)
+#define REPS8(OP) OP(0); OP(1); OP(2); OP(3); OP(4); OP(5); OP(6); OP(7)
 
 #define REP16(OP) OP(x[0]); OP(x[1]); OP(x[2]); OP(x[3]); OP(x[4]); OP(x[5]); OP(x[6]); OP(x[7]); OP(x[8]); OP(x[9]); OP(x[10]); OP(x[11]); OP(x[12]); OP(x[13]); OP(x[14]); OP(x[15])
 
-template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, float *sink, uint32_t trips, float fa, float fb) {
+template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, float *sink, uint32_t trips, float fa, float fb, const uint32_t *ktab) {
     __shared__ float4 s_tab[1024]; // 16 KB: ds_read_b128 targets (FMA_DSREAD, VISIT_*)
     for (uint32_t i = threadIdx.x; i < 1024; i += 256) s_tab[i] = make_float4(fa, fb, fa, fb);
     __syncthreads();
@@ -84,6 +90,12 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
     for (int k = 0; k < 8; ++k) y[k] = v2f{x[2 * k], x[2 * k + 1]};
     unsigned long long m = 0x5555aaaa3333ccccull, m2 = 0;
     uint32_t sc = 0;
+    uint32_t ss[16];
+    unsigned long long sm[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ss[k] = __builtin_amdgcn_readfirstlane(trips + k);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[k] = m ^ (0x0101010101010101ull * k);
     uint32_t addr = (threadIdx.x * 37u & 255u) * 64u; // per-lane node pair, 64 B apart
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (uint32_t it = 0; it < trips; ++it) {
@@ -148,6 +160,45 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
 #pragma unroll
             for (int k = 0; k < 64; ++k) { I_FMA(x[k & 15]); if (k & 1) I_SALU(); }
         }
+        if (KIND == S_ADD) { REPS16(I_SADD); REPS16(I_SADD); REPS16(I_SADD); REPS16(I_SADD); }
+        if (KIND == S_AND64) { REPS8(I_SAND64); REPS8(I_SAND64); REPS8(I_SAND64); REPS8(I_SAND64); REPS8(I_SAND64); REPS8(I_SAND64); REPS8(I_SAND64); REPS8(I_SAND64); }
+        if (KIND == S_CSEL) { REPS16(I_SCSEL); REPS16(I_SCSEL); REPS16(I_SCSEL); REPS16(I_SCSEL); }
+        if (KIND == S_LOADHIT) { // 64 scalar loads of one cached line, waited for every 16
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(ss[k & 15]) : "s"(ktab));
+                if ((k & 15) == 15) asm volatile("s_waitcnt lgkmcnt(0)");
+            }
+        }
+        if (KIND == RFL_CHAIN) { // v_readfirstlane -> s_add -> v_add with the scalar: the uniform() round trip, one dependent chain, 64 links (3 instructions each)
+#pragma unroll
+            for (int k = 0; k < 64; ++k)
+                asm volatile("v_readfirstlane_b32 %1, %0\n\ts_add_u32 %1, %1, 1\n\tv_add_u32 %0, %1, %0" : "+v"(x[0]), "+s"(sc) : : "scc");
+        }
+        if (KIND == FMA_SALU16) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) { I_FMA(x[k & 15]); if ((k & 3) == 3) I_SALU(); }
+        }
+        if (KIND == FMA_SALU64) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) { I_FMA(x[k & 15]); I_SADD(k & 15); }
+        }
+        if (KIND == FMA_SAND32) { // the traversal's scalar work is mostly 64-bit mask logic
+#pragma unroll
+            for (int k = 0; k < 64; ++k) { I_FMA(x[k & 15]); if (k & 1) I_SAND64((k >> 1) & 7); }
+        }
+        if (KIND == MINMAX_SALU32) { // half-rate VALU with a scalar instruction after every second one
+#pragma unroll
+            for (int k = 0; k < 64; ++k) { if (k & 1) { I_MIN(x[k & 15]); } else { I_MAX(x[k & 15]); } if (k & 1) I_SADD(k & 15); }
+        }
+        if (KIND == VISIT_MIX) { // the static mix of one inner visit of bounce_kernel (profiles/r03_isa_inner_visit.txt): 25 full-rate + 17 half-rate VALU, 32 SALU
+                                  // (two thirds of them 64-bit mask logic), interleaved; independent instructions, no LDS: what the issue logic alone allows
+#pragma unroll
+            for (int k = 0; k < 42; ++k) {
+                if (k % 5 < 3) { I_FMA(x[k & 15]); } else if (k & 1) { I_MIN(x[k & 15]); } else { I_CND(x[k & 15]); }
+                if (k < 32) { if (k % 3 == 0) { I_SADD(k & 15); } else { I_SAND64(k & 7); } }
+            }
+        }
         if (KIND == FMA_DSREAD) { // 64 v_fma + 4 ds_read_b128 per 64 (the node pair of one visit), waited for once per trip
             v4f n0, n1, n2, n3;
             asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48"
@@ -198,6 +249,10 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sc += ss[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sc += static_cast<uint32_t>(sm[k]);
     float s = static_cast<float>(m2 & 1) + static_cast<float>(sc) + static_cast<float>(addr) + s_tab[threadIdx.x].x; // (keeps s_tab allocated, at LDS offset 0)
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += x[k];
@@ -213,7 +268,7 @@ template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_o
         const int blocks = cus * waves_per_simd; // 256-thread blocks = 4 waves = one per SIMD; waves_per_simd blocks per CU
         // pick the trip count for ~8 ms launches, then hold the load for >= 0.7 s before the measured launches
         uint32_t trips = 2000;
-        auto launch = [&](uint32_t n) { hipLaunchKernelGGL(kern<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, n, 1.0001f, 0.5f); };
+        auto launch = [&](uint32_t n) { hipLaunchKernelGGL(kern<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, n, 1.0001f, 0.5f, reinterpret_cast<const uint32_t *>(d_sink)); };
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0)); launch(trips); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -253,7 +308,8 @@ template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_o
 }
 
 int main(int argc, char **argv) {
-    const bool only_new = argc > 1; // any argument: only the classes added last (packed FMA, fma_mix, perm, min_u32)
+    const bool only_new = argc > 1 && std::string(argv[1]) != "salu"; // "salu": the scalar classes of round 5; any other argument: only the classes added in round 3
+    const bool only_salu = argc > 1 && std::string(argv[1]) == "salu";
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -262,6 +318,25 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_out, sizeof(Stamp) * 4 * cus * 8));
     CK(hipMalloc(&d_sink, 64));
     printf("device: %s, %d CUs; cycles = s_memtime ticks, clock = s_memtime / s_memrealtime x 100 MHz, medians over all waves\n", prop.name, cus);
+    if (only_salu) {
+        // Does the scalar unit take issue slots from the vector ALU? Scalar classes alone, then VALU streams with 1/4, 1/2 and 1 scalar
+        // instruction per vector instruction (rates are per VALU instruction for the mixed rows, per scalar instruction for the pure ones).
+        quick = true;
+        run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);
+        run<S_ADD>("s_add_u32", 64, d_out, d_sink, cus);
+        run<S_AND64>("s_and_b64", 64, d_out, d_sink, cus);
+        run<S_CSEL>("s_cselect_b32", 64, d_out, d_sink, cus);
+        run<S_LOADHIT>("s_load_dword (scalar-cache hit)", 64, d_out, d_sink, cus);
+        run<RFL_CHAIN>("v_readfirstlane -> s_add -> v_add chain (per link)", 64, d_out, d_sink, cus);
+        run<FMA_SALU16>("64 v_fma + 16 s_add (per VALU)", 64, d_out, d_sink, cus);
+        run<FMA_SALU>("64 v_fma + 32 s_add (per VALU)", 64, d_out, d_sink, cus);
+        run<FMA_SALU64>("64 v_fma + 64 s_add (per VALU)", 64, d_out, d_sink, cus);
+        run<FMA_SAND32>("64 v_fma + 32 s_and_b64 (per VALU)", 64, d_out, d_sink, cus);
+        run<MINMAX>("v_min_f32 / v_max_f32", 64, d_out, d_sink, cus);
+        run<MINMAX_SALU32>("64 v_min/max + 32 s_add (per VALU)", 64, d_out, d_sink, cus);
+        run<VISIT_MIX>("visit mix: 25 full + 17 half VALU + 32 SALU (per VALU)", 42, d_out, d_sink, cus);
+        return 0;
+    }
     if (only_new) {
         quick = true;
         run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);

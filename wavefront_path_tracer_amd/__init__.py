@@ -31,6 +31,7 @@ SPP = 10  # wavefront_common/src/parameters.rs:4
 SPF = 1   # wavefront_common/src/parameters.rs:5
 
 RNG_DISPATCH, RNG_PIXEL = 0, 1
+LOOP_KINDS = ("stages", "fused", "fused_binned", "refill")  # wfpt_loop_kind
 FLAG_SPLIT_SHADE, FLAG_NO_GRAPH, FLAG_UNFUSED, FLAG_BINARY_BVH, FLAG_NO_REFILL, FLAG_NO_LDS_SCENE, FLAG_EXACT_TRAVERSAL, FLAG_NO_BINNING, FLAG_BINNING, FLAG_TWO_CHAINS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 INACTIVE_PIXEL = 0xFFFFFFFF
 # kernel.rs:32 loads shaders/{name}.wgsl; these are the stage names (path_tracer.rs:162,167,175,180,185)
@@ -249,6 +250,8 @@ def lib():
         "wfpt_comm_unique_id": (i32, [vp]),
         "wfpt_comm_init": (i32, [vp, vp, i32, i32]),
         "wfpt_gather_accumulated": (i32, [vp]),
+        "wfpt_gather_accumulated_timed": (i32, [vp, C.POINTER(f32)]),
+        "wfpt_loop_kind_of": (i32, [vp]),
         "wfpt_read_gathered": (i32, [vp, vp, sz]),
         "wfpt_comm_destroy": (i32, [vp]),
         "wfpt_read_rays": (i32, [vp, vp, u32]),
@@ -879,6 +882,20 @@ class PathTracer:
     def gather_accumulated(self):
         """Every rank: its slab goes to rank 0 over xGMI (asynchronous on the context's stream)."""
         self._check(lib().wfpt_gather_accumulated(self.handle))
+
+    def gather_accumulated_timed(self):
+        """The same gather, blocking; returns its duration on this rank in milliseconds (hipEvents on the context's stream)."""
+        ms = f32(0.0)
+        self._check(lib().wfpt_gather_accumulated_timed(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    @property
+    def loop_kind(self):
+        """Which loop render() enqueues: "stages", "fused", "fused_binned" or "refill" (wfpt_loop_kind_of)."""
+        k = lib().wfpt_loop_kind_of(self.handle)
+        if k < 0:
+            self._check(k)
+        return LOOP_KINDS[k]
 
     def gathered(self):
         """Rank 0: the assembled (width * height, 3) accumulated frame."""

@@ -1039,6 +1039,13 @@ const char *wfpt_build_info(void) {
     return info.c_str();
 }
 
+int wfpt_loop_kind_of(const wfpt_ctx *c) {
+    if (!c) return fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_loop_kind_of: null context");
+    if (!c->fused) return WFPT_LOOP_STAGES;
+    if (c->rec_dense && !c->scene.exact) return WFPT_LOOP_REFILL;
+    return use_binned(c) ? WFPT_LOOP_FUSED_BINNED : WFPT_LOOP_FUSED;
+}
+
 int wfpt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1927,6 +1934,20 @@ int wfpt_gather_accumulated(wfpt_ctx *c) {
         const size_t n_valid = r == 0 ? 3u * static_cast<size_t>(c->n_pixels) : nb * band_floats;
         WFPT_HIP(c, launch_band_scatter(c->gather_frame, src, n_valid, band_floats, world, r, c->stream));
     }
+    return WFPT_OK;
+}
+
+int wfpt_gather_accumulated_timed(wfpt_ctx *c, float *ms) {
+    if (!c || !ms) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_gather_accumulated_timed: null argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream)); // the gather's own time, not the tail of what was queued before it
+    if (int r = stage_begin(c, WFPT_STAGE_ACCUMULATE); r != WFPT_OK) return r; // (borrows that stage's event pair; nothing is pending after the synchronize)
+    const int r = wfpt_gather_accumulated(c);
+    StageTimer &t = c->timers[WFPT_STAGE_ACCUMULATE];
+    WFPT_HIP(c, hipEventRecord(t.stop, c->stream));
+    WFPT_HIP(c, hipEventSynchronize(t.stop));
+    if (r != WFPT_OK) return r;
+    WFPT_HIP(c, hipEventElapsedTime(ms, t.start, t.stop));
     return WFPT_OK;
 }
 

@@ -656,6 +656,138 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 // the left child; the far one pending). Infinite inverses (a direction component that is exactly zero) are clamped to
 // +-1e30 for the inner boxes: the two planes of such an axis then read "always" or "never" like the reference's +-inf,
 // without inf - inf; the leaf test uses the unclamped inverse, as the reference does.
+#ifndef WFPT_WALK_ASM
+#define WFPT_WALK_ASM 1 // 1: the inner-node loop of the LDS walk (32-bit trail) as hand-written gfx950 assembly (descend_asm); 0: the compiler's loop
+#endif
+// LDS byte offset of a pointer into the workgroup's dynamic LDS (the operand of a ds_read)
+__device__ __forceinline__ uint32_t lds_offset(const void *p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((WFPT_AS_LDS const char *)p));
+}
+// The inner-node loop of trace_ray_conservative -- every lane that sits on an inner node (prim_count == 0) visits node pairs until it sits
+// on a leaf or its walk is over (prim_count = kWalkDone) -- written by hand, because what bounds the launch is instruction ISSUE, of both
+// kinds: hipcc's structurizer turns the loop nest (visit | pop with its parent-table walk) into 34-36 scalar mask instructions and
+// 46-47 vector instructions per visit; this loop has 11 scalar and 36 vector ones on the descending path. Same operations on the same
+// values as the C++ statement of the visit (the #else branch below; WFPT_WALK_ASM=0 builds it), in the instruction selection hipcc itself
+// chose for them (v_max3 / v_min / v_min3 / source modifiers), so both give the same bits:
+//   per box: tc = c * b + (-o * b); t_in = max3(tc - h |b|); t_out = min(min(tcx + hx |bx|, tcy + hy |by|), tcz + hz |bz|, nearest)
+//            entered <=> max(t_in, 0) <= t_out
+//   go_right = hit_r & (!hit_l | l_in > r_in); both -> the far child stays pending (trail bit); none -> pop
+//   pop: nothing pending -> done; else climb `ffbl(trail)` levels through the u16 parent table, take the sibling, read its fields.
+// exec is narrowed to the lanes still in the loop and restored at the end. The node pair lands in v[48:63], named in the clobber list (an
+// inline-asm operand cannot name the components of a 128-bit register tuple).
+__device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_lds, float bx, float by, float bz, float nox, float noy, float noz,
+                                            float nearest, uint32_t &node, uint32_t &left_first, uint32_t &prim_count, uint32_t &trail) {
+    unsigned long long m_save, m_cur, m_l, m_r, m_go, m_t;
+    float t1, t2; // every other temporary is a register of the node pair whose value has been consumed (the kernel has 64 vector registers)
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[pc]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lwfpt_end%=\n"
+        ".Lwfpt_loop%=:\n\t"
+        "v_lshl_add_u32 %[t2], %[lf], 5, %[nodes]\n\t"
+        "ds_read_b128 v[48:51], %[t2]\n\t"            // left:  centre.xyz | left_first
+        "ds_read_b128 v[52:55], %[t2] offset:16\n\t"  //        half.xyz   | prim_count
+        "ds_read_b128 v[56:59], %[t2] offset:32\n\t"  // right: centre.xyz | left_first
+        "ds_read_b128 v[60:63], %[t2] offset:48\n\t"  //        half.xyz   | prim_count
+        "s_mov_b64 %[cur], exec\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_fma_f32 v48, v48, %[bx], %[nox]\n\t"       // tc = c * b - o * b
+        "v_fma_f32 v49, v49, %[by], %[noy]\n\t"
+        "v_fma_f32 v50, v50, %[bz], %[noz]\n\t"
+        "v_fma_f32 %[t1], v52, -|%[bx]|, v48\n\t"     // entry distances tc - h |b| ...
+        "v_fma_f32 v48, v52, |%[bx]|, v48\n\t"        // ... exit distances tc + h |b|
+        "v_fma_f32 v52, v53, -|%[by]|, v49\n\t"
+        "v_fma_f32 v49, v53, |%[by]|, v49\n\t"
+        "v_fma_f32 v53, v54, -|%[bz]|, v50\n\t"
+        "v_fma_f32 v50, v54, |%[bz]|, v50\n\t"
+        "v_max3_f32 %[t1], %[t1], v52, v53\n\t"       // l_in
+        "v_min_f32_e32 v48, v48, v49\n\t"
+        "v_min3_f32 v48, v48, v50, %[nearest]\n\t"
+        "v_max_f32_e32 v49, 0, %[t1]\n\t"
+        "v_cmp_le_f32_e64 %[ml], v49, v48\n\t"        // hit_l
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_fma_f32 v56, v56, %[bx], %[nox]\n\t"
+        "v_fma_f32 v57, v57, %[by], %[noy]\n\t"
+        "v_fma_f32 v58, v58, %[bz], %[noz]\n\t"
+        "v_fma_f32 %[t2], v60, -|%[bx]|, v56\n\t"
+        "v_fma_f32 v56, v60, |%[bx]|, v56\n\t"
+        "v_fma_f32 v60, v61, -|%[by]|, v57\n\t"
+        "v_fma_f32 v57, v61, |%[by]|, v57\n\t"
+        "v_fma_f32 v61, v62, -|%[bz]|, v58\n\t"
+        "v_fma_f32 v58, v62, |%[bz]|, v58\n\t"
+        "v_max3_f32 %[t2], %[t2], v60, v61\n\t"       // r_in
+        "v_min_f32_e32 v56, v56, v57\n\t"
+        "v_min3_f32 v56, v56, v58, %[nearest]\n\t"
+        "v_max_f32_e32 v57, 0, %[t2]\n\t"
+        "v_cmp_le_f32_e64 %[mr], v57, v56\n\t"        // hit_r
+        "v_cmp_gt_f32_e32 vcc, %[t1], %[t2]\n\t"      // r_nearer = l_in > r_in
+        "s_orn2_b64 %[mt], vcc, %[ml]\n\t"
+        "s_and_b64 %[mgo], %[mt], %[mr]\n\t"          // go_right = hit_r & (r_nearer | !hit_l)
+        "s_or_b64 %[mt], %[ml], %[mr]\n\t"            // entered at all
+        "s_and_b64 %[ml], %[ml], %[mr]\n\t"           // both
+        // ---- descend (lanes that entered a child)
+        "s_and_b64 exec, %[cur], %[mt]\n\t"
+        "v_addc_co_u32_e64 %[node], %[mr], 0, %[lf], %[mgo]\n\t" // node = left_first + go_right (the carry out is not used)
+        "v_cndmask_b32_e64 %[t2], 0, 1, %[ml]\n\t"
+        "v_lshl_or_b32 %[trail], %[trail], 1, %[t2]\n\t"
+        "v_cndmask_b32_e64 %[lf], v51, v59, %[mgo]\n\t"
+        "v_cndmask_b32_e64 %[pc], v55, v63, %[mgo]\n\t"
+        // ---- pop (lanes that entered neither)
+        "s_andn2_b64 exec, %[cur], %[mt]\n\t"
+        "s_cbranch_execz .Lwfpt_next%=\n\t"
+        "v_mov_b32_e32 %[pc], -1\n\t"                 // nothing pending: the walk is over (kWalkDone)
+        "v_cmp_ne_u32_e32 vcc, 0, %[trail]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lwfpt_next%=\n\t"
+        "v_ffbl_b32_e32 %[t1], %[trail]\n\t"          // levels to climb to the deepest pending sibling
+        "s_mov_b64 %[mr], exec\n\t"
+        "v_lshrrev_b32_e32 %[trail], %[t1], %[trail]\n\t"
+        "v_and_b32_e32 %[trail], -2, %[trail]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lwfpt_climbed%=\n"
+        ".Lwfpt_climb%=:\n\t"
+        "v_and_b32_e32 %[t2], -2, %[node]\n\t"        // pair_parent[node >> 1], u16 entries
+        "v_add_u32_e32 %[t2], %[parent], %[t2]\n\t"
+        "ds_read_u16 %[node], %[t2]\n\t"
+        "v_add_u32_e32 %[t1], -1, %[t1]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execnz .Lwfpt_climb%=\n"
+        ".Lwfpt_climbed%=:\n\t"
+        "s_mov_b64 exec, %[mr]\n\t"
+        "v_xor_b32_e32 %[node], 1, %[node]\n\t"
+        "v_lshl_add_u32 %[t2], %[node], 5, %[nodes]\n\t"
+        "ds_read_b32 %[lf], %[t2] offset:12\n\t"
+        "ds_read_b32 %[pc], %[t2] offset:28\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        ".Lwfpt_next%=:\n\t"
+        "s_mov_b64 exec, %[cur]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[pc]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execnz .Lwfpt_loop%=\n"
+        ".Lwfpt_end%=:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [node] "+v"(node), [lf] "+v"(left_first), [pc] "+v"(prim_count), [trail] "+v"(trail), [save] "=&s"(m_save), [cur] "=&s"(m_cur),
+          [ml] "=&s"(m_l), [mr] "=&s"(m_r), [mgo] "=&s"(m_go), [mt] "=&s"(m_t), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [nodes] "s"(nodes_lds), [parent] "s"(parent_lds), [bx] "v"(bx), [by] "v"(by), [bz] "v"(bz), [nox] "v"(nox), [noy] "v"(noy), [noz] "v"(noz),
+          [nearest] "v"(nearest)
+        : "vcc", "scc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
+#ifndef WFPT_WALK_V1
+#define WFPT_WALK_V1 0 // 1: the loop nest of rounds 3-4 (a Traversal object, an `alive` flag): measurement builds only
+#endif
+// Round 5: the walk's state is four vector registers and NO boolean. The scalar unit of a CU serves its four SIMDs with about one
+// instruction per cycle (tools/microbench_valu.hip salu: 0.55 per ns per SIMD), and the loop nest of rounds 3-4 -- an `alive` flag carried
+// through two nested loops and an if / else per visit -- compiled to 36 scalar instructions (exec-mask bookkeeping) per 46 vector
+// instructions of a visit: the static mix ran at 0.61 vector instructions per ns per SIMD where the vector instructions alone would reach
+// 0.75 (profiles/r05_microbench_salu.txt), and the launch's scalar unit was 58 % busy. Here a finished walk is a value of prim_count
+// (kWalkDone) instead of a flag, so both loop conditions are one vector compare each, the descent is computed for every lane and
+// overwritten by the (one-sided) pop, and nothing but the exec mask itself lives in scalar registers across an iteration.
+constexpr uint32_t kWalkDone = 0xffffffffu; // prim_count of a lane whose walk has ended (a scene in LDS holds fewer than 2^16 primitives)
 template <typename Trail, int PRIM, typename ParentT>
 __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, const float4 *prim_geom, const ParentT *pair_parent, float ox,
                                                        float oy, float oz, float dx, float dy, float dz, uint32_t max_steps, float &t_out,
@@ -666,6 +798,7 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
     const float ax = __builtin_fabsf(bx), ay = __builtin_fabsf(by), az = __builtin_fabsf(bz);
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
+#if WFPT_WALK_V1
     Traversal<Trail, ParentT, 0> tr;
     tr.node = 0; // ex:84: the root's box is never tested
     tr.left_first = __float_as_uint(nodes_ch[0].w);
@@ -714,6 +847,80 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
             alive = tr.pop(nodes_ch, pair_parent);
         }
     }
+#else
+    uint32_t node = 0; // ex:84: the root's box is never tested
+    uint32_t left_first = __float_as_uint(nodes_ch[0].w), prim_count = __float_as_uint(nodes_ch[1].w);
+    Trail trail = 0; // bit i: the far sibling is still pending at the path node i levels above the current one (see Traversal)
+    const bool root_leaf = prim_count != 0u; // the root's own box is never tested (ex:84)
+    uint32_t best_leaf = 0; // the leaf of `best`: left_first | prim_count << 16
+    uint32_t budget = max_steps; // see trace_ray
+    const uint32_t nodes_lds = uniform(lds_offset(nodes_ch)), parent_lds = uniform(lds_offset(pair_parent));
+    // LIFO pop (Traversal::pop): the deepest pending sibling, found by walking the parent table up from the current node; nothing
+    // pending ends the walk (ex:95-97, 125-127: break)
+#define WFPT_POP()                                                                                                                     \
+    do {                                                                                                                               \
+        if (trail == 0) {                                                                                                              \
+            prim_count = kWalkDone;                                                                                                    \
+        } else {                                                                                                                       \
+            const uint32_t up = (sizeof(Trail) == 8) ? static_cast<uint32_t>(__ffsll(static_cast<long long>(trail)) - 1)              \
+                                                     : static_cast<uint32_t>(__ffs(static_cast<int>(trail)) - 1);                      \
+            trail = (trail >> up) & ~static_cast<Trail>(1);                                                                            \
+            for (uint32_t k = 0; k < up; ++k) node = pair_parent[node >> 1];                                                           \
+            node ^= 1u;                                                                                                                \
+            left_first = __float_as_uint(nodes_ch[2u * node].w);                                                                       \
+            prim_count = __float_as_uint(nodes_ch[2u * node + 1u].w);                                                                  \
+        }                                                                                                                              \
+    } while (0)
+    while (prim_count != kWalkDone) {
+        if (WFPT_WALK_ASM && !WFPT_STAMPS && sizeof(Trail) == 4 && sizeof(ParentT) == 2) { // inner nodes (ex:105-138), hand-written loop
+            uint32_t trail32 = static_cast<uint32_t>(trail);
+            descend_asm(nodes_lds, parent_lds, bx, by, bz, nox, noy, noz, nearest, node, left_first, prim_count, trail32);
+            trail = static_cast<Trail>(trail32);
+        } else
+        while (prim_count == 0u) { // inner nodes (ex:105-138)
+#if WFPT_BUDGET_INNER
+            if (budget-- == 0) { prim_count = kWalkDone; break; }
+#endif
+#if WFPT_STAMPS
+            dbg[0] = __builtin_amdgcn_readfirstlane(dbg[0]) + 1u;
+            dbg[2] += 1u;
+#endif
+            const float4 *pair = nodes_ch + 2u * left_first;
+            const float4 lc = pair[0], lh = pair[1], rc = pair[2], rh = pair[3];
+            keep4(lc, lh, rc, rh);
+            const float lcx = fma_(lc.x, bx, nox), lcy = fma_(lc.y, by, noy), lcz = fma_(lc.z, bz, noz);
+            const float l_in = max_(max_(fma_(lh.x, -ax, lcx), fma_(lh.y, -ay, lcy)), fma_(lh.z, -az, lcz));
+            const float l_out = min_(min_(fma_(lh.x, ax, lcx), fma_(lh.y, ay, lcy)), fma_(lh.z, az, lcz));
+            const float rcx = fma_(rc.x, bx, nox), rcy = fma_(rc.y, by, noy), rcz = fma_(rc.z, bz, noz);
+            const float r_in = max_(max_(fma_(rh.x, -ax, rcx), fma_(rh.y, -ay, rcy)), fma_(rh.z, -az, rcz));
+            const float r_out = min_(min_(fma_(rh.x, ax, rcx), fma_(rh.y, ay, rcy)), fma_(rh.z, az, rcz));
+            const bool hit_l = max_(l_in, 0.0f) <= min_(l_out, nearest);
+            const bool hit_r = max_(r_in, 0.0f) <= min_(r_out, nearest);
+            const bool r_nearer = l_in > r_in;
+            const bool go_right = hit_r && (!hit_l || r_nearer); // nearer entry first; ties keep the left child (ex:119)
+            if (hit_l || hit_r) { // descend; both entered: the far one stays pending
+                node = left_first + (go_right ? 1u : 0u);
+                trail = (trail << 1) | static_cast<Trail>((hit_l && hit_r) ? 1u : 0u);
+                left_first = __float_as_uint(go_right ? rc.w : lc.w);
+                prim_count = __float_as_uint(go_right ? rh.w : lh.w);
+            } else {
+                WFPT_POP();
+            }
+        }
+        if (prim_count != kWalkDone) { // leaf (ex:86-103)
+            if (budget-- == 0) {
+                prim_count = kWalkDone;
+            } else {
+#if WFPT_STAMPS
+                dbg[1] = __builtin_amdgcn_readfirstlane(dbg[1]) + 1u;
+#endif
+                visit_leaf<PRIM>(prim_geom, left_first, prim_count, left_first | (prim_count << 16), ox, oy, oz, dx, dy, dz, a, nearest, best, best_leaf);
+                WFPT_POP();
+            }
+        }
+    }
+#undef WFPT_POP
+#endif
     leaf_box_verdict<PRIM>(prim_geom, best_leaf & 0xffffu, best_leaf >> 16, root_leaf, ox, oy, oz, dx, dy, dz, nearest, best);
     t_out = nearest;
     prim_out = best; // kHandOver: the caller re-traces with the reference's walk
