@@ -47,7 +47,7 @@ B_MISS = 36.0                                                # miss_kernel: inde
 B_GENERATE_PIXEL = 28.0 + 12.0                               # generate_rays: ray written + image reset folded in
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="timed frames (one step = one frame of --spp samples per pixel)")
@@ -67,9 +67,8 @@ def parse():
     ap.add_argument("--no-lds-scene", action="store_true", help="experiment: traverse the scene from HBM / L2 although it fits LDS")
     ap.add_argument("--no-binning", action="store_true",
                     help="WFPT_FLAG_NO_BINNING (pixel-keyed RNG): the hit queue stays in thread order (a work item = 512 consecutive hits) instead of being binned by cost class")
-    ap.add_argument("--two-chains", action="store_true", help="WFPT_FLAG_TWO_CHAINS (experiment): a batch as two overlapping half-batches on two streams")
     ap.add_argument("--binning", action="store_true",
-                    help="WFPT_FLAG_BINNING: the class-binned loop in the dispatch-keyed RNG mode too (thread indices carried; same image, slower there)")
+                    help="WFPT_FLAG_BINNING (pixel-keyed RNG only): the class-binned loop whatever the size of the slab")
     ap.add_argument("--no-refill", action="store_true", help="mesh scene: fused bounce kernel (lanes keep their ray) instead of dynamic lane refill")
     ap.add_argument("--binary-bvh", action="store_true", help="mesh scene: walk the binary tree instead of the four-wide collapse")
     ap.add_argument("--unfused", action="store_true", help="run the stage kernels one by one (extend, scan, shade, miss_kernel per wavefront)")
@@ -90,7 +89,7 @@ def parse():
     ap.add_argument("--force-rccl", action="store_true",
                     help="N = 1: run the RCCL branch anyway (unique id -> comm_init -> gather -> gathered) with a one-rank communicator")
     ap.add_argument("--dump", default=None, help="write the tone-mapped frame (PPM) here (rank 0)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def self_launch(args):
@@ -195,17 +194,46 @@ def provenance(W, gpu_index):
             "device": dev.get("name"), "date_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ")}
 
 
-def load_pmc(scene, variant):
+def workload_key(args, world=1):
+    """What has to be equal for a committed profile to be a profile OF THIS RUN: the scene and its size, the frame, the samples per
+    pixel and in flight, the bounces, the seed, the RNG mode and the number of ranks the frame is cut into."""
+    fused = not (args.split_shade or args.unfused)
+    batch = args.batch or min(args.spp, 128 if fused else 64)
+    mode = args.rng_mode if args.rng_mode != "auto" else ("dispatch" if world == 1 else "pixel")
+    return {"scene": args.scene, "triangles": args.triangles if args.scene == "mesh" else None, "width": args.width, "height": args.height,
+            "spp": args.spp, "bounces": args.bounces, "seed": args.seed, "rng_mode": mode, "samples_in_flight": min(batch, args.spp), "ranks": world}
+
+
+def profile_workload(pmc):
+    """The workload a committed profile was taken on: the key it carries (profiles written since round 5), else re-derived from the bench
+    command it records (the command line goes through this file's own parser); None if neither can be had."""
+    if isinstance(pmc.get("workload_key"), dict):
+        return pmc["workload_key"]
+    cmd = (pmc.get("bench_command") or "").split()
+    if "bench.py" not in [os.path.basename(c) for c in cmd]:
+        return None
+    argv = cmd[[os.path.basename(c) for c in cmd].index("bench.py") + 1:]
+    try:
+        a = parse(argv)
+    except SystemExit:
+        return None
+    return workload_key(a, max(a.gpus, 1))
+
+
+def load_pmc(scene, variant, key=None):
     """Committed rocprofv3 --pmc summary of THIS workload and loop variant (profiles/r*_pmc_<scene>_<variant>.json,
-    written by profiles/summarize_rocprof.py from the same bench command), newest round first; None if there is none."""
+    written by profiles/summarize_rocprof.py from the same bench command), newest round first; None if there is none. With `key`
+    (workload_key of the run at hand) a profile of any other workload -- another frame size, spp, scene size, RNG mode ... -- is no match."""
     import glob
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{scene}_{variant}.json")), reverse=True):
         try:
             d = json.load(open(p))
-            d["source"] = os.path.relpath(p, ROOT)
-            return d
         except Exception:
             continue
+        if key is not None and profile_workload(d) != key:
+            continue
+        d["source"] = os.path.relpath(p, ROOT)
+        return d
     return None
 
 
@@ -246,7 +274,7 @@ def main():
     flags = ((W.FLAG_SPLIT_SHADE if args.split_shade else 0) | (W.FLAG_NO_GRAPH if args.no_graph else 0) |
              (W.FLAG_UNFUSED if args.unfused else 0) | (W.FLAG_BINARY_BVH if args.binary_bvh else 0) |
              (W.FLAG_NO_REFILL if args.no_refill else 0) | (W.FLAG_NO_LDS_SCENE if args.no_lds_scene else 0) |
-             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0) | (W.FLAG_NO_BINNING if args.no_binning else 0) | (W.FLAG_BINNING if args.binning else 0) | (W.FLAG_TWO_CHAINS if args.two_chains else 0))
+             (W.FLAG_EXACT_TRAVERSAL if args.exact_traversal else 0) | (W.FLAG_NO_BINNING if args.no_binning else 0) | (W.FLAG_BINNING if args.binning else 0))
     # samples in flight per launch = the whole frame's samples (64): the late wavefronts are small, and a launch of few work
     # items per workgroup ends on a long tail (32 / 64 / 128 in flight: 18.8 / 19.4 / 19.6 Grays/s on a 128-spp job)
     fused = not (args.split_shade or args.unfused)
@@ -260,6 +288,8 @@ def main():
     else:
         pt = W.shirley_path_tracer(args.width, args.height, **kw)
         scene_name = f"Shirley random-spheres (scene.rs:48-107, seed {args.seed})"
+
+    loop_kind = pt.loop_kind  # the loop this context enqueues, as the library decided it (flags, RNG mode, slab size, scene)
 
     def sync():
         pt.synchronize()
@@ -338,6 +368,8 @@ def main():
     frame = None
     for _ in range(args.steps):        # EXACTLY K steps
         frame = render_frame(args.spp)
+    pt.synchronize()
+    own_elapsed = time.perf_counter() - t0  # this rank's own K steps, its leg of the gather included, before it waits for the others
     sync()
     elapsed = time.perf_counter() - t0
     rays = pt.totals() - rays0     # [rays traced by extend, hits, misses] on this rank
@@ -355,6 +387,42 @@ def main():
             frame = pt.gathered()  # outside the timed region: the frame crosses PCIe only for the dump / the check
     elif world == 1:
         frame = pt.accumulated()
+    # ---- where an N > 1 figure comes from ("scaling factor, gather time"), all OUTSIDE the timed region:
+    #   rank_ms_per_step         every rank's own wall time per step of the timed loop (its renders + its leg of the gather)
+    #   rank_render_ms_per_step  the same K frames once more WITHOUT the gather, every rank timing itself: what the slab costs
+    #   gather_ms                one gather timed alone, every rank idle when it starts (hipEvent pair on the context's stream behind the
+    #                            C ABI, wfpt_gather_accumulated_timed; the gloo rehearsal: wall time of the host-memory gather)
+    #   value_per_rank_ceiling   the job's rays / the slowest rank's render time: N x the slowest rank, the curve's ceiling before the gather
+    scaling_detail = None
+    if world > 1 or use_rccl:
+        def per_rank(x):
+            if dist is None:
+                return [float(x)]
+            xs = [None] * world
+            dist.all_gather_object(xs, float(x))
+            return xs
+        rank_ms = per_rank(own_elapsed / args.steps * 1e3)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pt.reset_progress()
+            pt.render(args.spp)
+        pt.synchronize()
+        render_ms = per_rank((time.perf_counter() - t1) / args.steps * 1e3)
+        sync()
+        if use_rccl:
+            g_ms = pt.gather_accumulated_timed()
+        else:
+            t2 = time.perf_counter()
+            frame = gather()
+            g_ms = (time.perf_counter() - t2) * 1e3
+        gather_ms = per_rank(g_ms)
+        sync()
+        scaling_detail = {"rank_ms_per_step": [round(x, 4) for x in rank_ms], "rank_render_ms_per_step": [round(x, 4) for x in render_ms],
+                          "gather_ms": round(max(gather_ms), 4), "gather_ms_per_rank": [round(x, 4) for x in gather_ms],
+                          "gather_ms_note": ("one gather timed alone after a barrier, every rank idle at its start; hipEvent pair around wfpt_gather_accumulated "
+                                             "on each rank's stream (rank 0: the receives + the de-interleave; peers: their send), outside the timed region"
+                                             if use_rccl else "REHEARSAL: wall time of the gloo gather through host memory, outside the timed region")}
     gather_check = None
     if world > 1:
         # The gather's send / receive legs have no multi-GPU test on the one-GPU boxes this is developed on, so every N > 1 run
@@ -443,12 +511,13 @@ def main():
                 first = ("refill_kernel<first> (four-wide extend of wavefront 0, dynamic lane refill; its primary rays come from generate_dense_kernel)",
                          B_EXTEND_RAY * rays_0 + B_EXTEND_HIT * hits_0 + B_EXTEND_MISS * miss_0, 64.0 * rays_0)
             else:
-                mid = ("bounce_kernel<middle> (shade + extend + miss_kernel of one wavefront)",
+                kn = "bounce_binned_kernel" if loop_kind == "fused_binned" else "bounce_kernel"
+                mid = (kn + "<middle> (shade + extend + miss_kernel of one wavefront)",
                        B_SHADE_HIT * shaded + B_EXTEND_RAY * rays_k + B_EXTEND_HIT * hits_out + B_EXTEND_MISS * miss_out + B_MISS * applied,
                        # what the fused design itself has to move: record in (32), throughput RMW (2 x 16, padded pixels), record out
                        # (32) / miss out (8), applied miss (8 + 32) -- no extension-ray queue, no hit-queue gather
                        64.0 * shaded + 32.0 * hits_out + 8.0 * miss_out + 40.0 * applied)
-                first = ("bounce_kernel<first> (generate_rays + extend of wavefront 0)",
+                first = (kn + "<first> (generate_rays + extend of wavefront 0)",
                          B_GENERATE_PIXEL * pixels + B_EXTEND_RAY * rays_0 + B_EXTEND_HIT * hits_0 + B_EXTEND_MISS * miss_0,
                          16.0 * pixels + 32.0 * hits_0 + 8.0 * miss_0)  # image reset (16, padded pixel), record / miss out: the ray never leaves registers
             first_dominant = ms[W.STAGES["bounce_first"]] > ms[W.STAGES["bounce"]]
@@ -491,10 +560,10 @@ def main():
                    "step": (f"one frame: accumulation reset, {args.spp} samples per pixel (each generate_rays -> {args.bounces} x (extend, scan, "
                             "shade, miss_kernel) -> accumulate)" + (", one gather of the frame to rank 0" if world > 1 else "")),
                    "rng_mode": mode_name, "shade": "per-material" if args.split_shade else "unified",
-                   "loop": ("fused bounce launches" + (", hit queue binned by cost class (work item = 512 hits of one class)"
-                                                         if (args.scene == "shirley" and not args.no_lds_scene and
-                                                             (args.binning if mode_name == "dispatch" else not args.no_binning)) else ""))
-                           if fused else "stage kernels one by one",
+                   "loop": {"stages": "stage kernels one by one", "fused": "fused bounce launches, hit queue in thread order",
+                            "fused_binned": "fused bounce launches, hit queue binned by cost class (work item = 512 hits of one class)",
+                            "refill": "four-wide traversal with dynamic lane refill (generate / shade / compact as launches of their own)"}[loop_kind],
+                   "loop_kind": loop_kind,
                    "traversal": (("LDS-resident binary BVH" + (", reference slab arithmetic (exact-traversal)" if args.exact_traversal else ""))
                                  if args.scene == "shirley" and not args.no_lds_scene else
                                  ("binary BVH from HBM" if (args.binary_bvh or args.scene == "shirley") else
@@ -511,7 +580,14 @@ def main():
                                        "the first multi-GPU run verifies them itself (gather_check)"),
                    "rays_traced": int(rays_total[0])},
     }
+    if scaling_detail is not None:
+        slowest = max(scaling_detail["rank_render_ms_per_step"])
+        scaling_detail["value_per_rank_ceiling"] = round(float(rays_total[0]) / args.steps / (slowest * 1e-3) / 1e6, 3) if slowest > 0 else None
+        scaling_detail["value_per_rank_ceiling_note"] = ("rays of one step / the slowest rank's render time without the gather (= N x the slowest rank): what "
+                                                          "`value` would be with a free gather; value / this = the gather's and the barrier's share")
+        out.update(scaling_detail)
     out["provenance"] = provenance(W, gpu_index)
+    out["workload_key"] = workload_key(args, world)
     if pixel_anchor is not None:
         out["value_pixel_mode"] = pixel_anchor["value"]
         out["config"]["rng_mode_anchor"] = pixel_anchor["note"]
@@ -531,14 +607,14 @@ def main():
             variant += "_nolds"
         if args.exact_traversal:
             variant += "_exact"
-        binned = fused and args.scene == "shirley" and not args.no_lds_scene and (args.binning if mode_name == "dispatch" else not args.no_binning)
+        binned = loop_kind == "fused_binned"  # what the context really enqueues (wfpt_loop_kind_of), not what the flags suggest
         if binned:
             variant += "_binned"
-        pmc = load_pmc(args.scene, variant)
         # PMC counters cannot be collected inside a plain run: `traffic` and `secondary` come from the committed rocprofv3
-        # profile of THIS command (same scene, loop variant and samples in flight) and are labelled as such
-        same_shape = bool(pmc) and pmc.get("samples_in_flight") == min(batch, args.spp)
-        per_kernel = ((pmc or {}).get("launches") or {}) if same_shape else {}
+        # profile of THIS command -- same scene and size, frame, samples per pixel and in flight, bounces, RNG mode, ranks and loop
+        # variant (workload_key) -- and are labelled as such; a profile of any other workload is no match and the fields stay null
+        pmc = load_pmc(args.scene, variant, workload_key(args, world))
+        per_kernel = ((pmc or {}).get("launches") or {})
         pk = per_kernel.get(stage["kstage"], {})
         fabric = pk.get("fabric_bytes_per_launch")
         lds_scene = args.scene == "shirley" and not args.no_lds_scene

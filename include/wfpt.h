@@ -195,18 +195,17 @@ enum {
                                         the range that bound covers. Same images bit for bit; for bisecting and proofs. */
     WFPT_FLAG_NO_BINNING = 1u << 7,  /* WFPT_RNG_PIXEL, scenes in LDS: keep the hit queue in thread order (a work item of the fused
                                         loop = 512 consecutive hits) instead of storing every segment's hits sorted by cost class
-                                        (the dominant primitive | material) and shading / tracing 512 hits of ONE class per work
-                                        item, which is the default there for contexts of at least 3/4 Mpixel (+2.3 % measured at
-                                        1920x1080; smaller slabs lose to the partly filled work items). Same images bit for bit. */
-    WFPT_FLAG_BINNING = 1u << 8,     /* run the class-binned loop whatever the size, and in WFPT_RNG_DISPATCH too. The reference's order survives -- every
-                                        ray carries its thread index, extend leaves a hit flag per thread index, the scan turns
-                                        the flags into a rank table and shade's thread index (shade.wgsl:72) is recovered from it
-                                        -- so the images are the same bit for bit; but carrying the order costs what the binning
-                                        gains (-5.8 % measured), hence off by default. */
-    WFPT_FLAG_TWO_CHAINS = 1u << 9   /* experiment: run a batch of the fused loop as its two halves, two chains of launches on two
-                                        streams (two branches of the captured graph), so that the tail of one half's launch
-                                        overlaps with the bulk of the other's. Samples are independent: same images bit for bit.
-                                        Measured slower at every slab size (profiles/r04_rejected_experiments.txt): off by default. */
+                                        (the dominant primitive | lambertian | metal | dielectric) and shading / tracing 512 hits of
+                                        ONE class per work item -- the default there for contexts of at least 3/4 Mpixel (+2 %
+                                        measured at 1920x1080; smaller slabs lose to the partly filled work items). Same images bit
+                                        for bit. */
+    WFPT_FLAG_BINNING = 1u << 8      /* WFPT_RNG_PIXEL only: run the class-binned loop whatever the size of the context. With
+                                        WFPT_RNG_DISPATCH wfpt_create refuses the flag (WFPT_ERR_INVALID_ARGUMENT): shade.wgsl:72 keys
+                                        its RNG on the dispatch's thread index, i.e. on the order of the hit queue, which this loop
+                                        gives up. (Round 4 carried that order through the binning -- thread indices in the records, a hit
+                                        flag per ray, a rank table per wavefront -- measured it 5.8 % slower than the thread-ordered loop
+                                        and round 5 removed it; so was the two-chain experiment, WFPT_FLAG_TWO_CHAINS, bit 9:
+                                        profiles/r04_rejected_experiments.txt.) */
 };
 
 #define WFPT_INACTIVE_PIXEL 0xffffffffu

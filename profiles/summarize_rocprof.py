@@ -105,6 +105,7 @@ def main():
                "git_head": prov.get("git_head"), "git_dirty_at_build": prov.get("git_dirty_at_build"), "source_sha256": prov.get("source_sha256"),
                "device": prov.get("device"), "date_utc": prov.get("date_utc"),
                "samples_in_flight": batches[0] if len(batches) == 1 else batches,
+               "workload_key": line.get("workload_key"),  # bench.py matches a run to a profile by this (scene and size, frame, spp, bounces, RNG mode, ranks)
                "fetch_calibration": {"streaming_16B_per_lane_on_accumulate": cal_stream, "gather_64B_records": cal_gather,
                                      "gather_source": cal_gather_src},
                "launches": {}}

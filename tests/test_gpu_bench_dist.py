@@ -38,6 +38,12 @@ def test_two_rank_rehearsal_equals_single_rank(gpu, tmp_path):
     assert a["config"]["rays_traced"] == b["config"]["rays_traced"]  # the same rays, split over two ranks
     assert a["config"]["gather_check"] is None and b["config"]["gather_check"].startswith("every rank's slab equals")  # bench's own check of the gather
     assert one.read_bytes() == two.read_bytes()
+    # where an N > 1 figure comes from: every rank's own time, the slab's render time, the gather timed alone
+    assert "gather_ms" not in a and "rank_ms_per_step" not in a
+    assert len(b["rank_ms_per_step"]) == 2 and len(b["rank_render_ms_per_step"]) == 2 and len(b["gather_ms_per_rank"]) == 2
+    assert all(x > 0 for x in b["rank_ms_per_step"] + b["rank_render_ms_per_step"]) and b["gather_ms"] == max(b["gather_ms_per_rank"]) > 0
+    assert "REHEARSAL" in b["gather_ms_note"]
+    assert b["value_per_rank_ceiling"] == pytest.approx(b["config"]["rays_traced"] / b["steps"] / (max(b["rank_render_ms_per_step"]) * 1e-3) / 1e6, rel=1e-3)
 
 
 def test_rccl_branch_of_bench_with_a_one_rank_communicator(gpu):
@@ -51,6 +57,10 @@ def test_rccl_branch_of_bench_with_a_one_rank_communicator(gpu):
     line = last_json_line(r.stdout)
     assert line["n_gpus"] == 1 and "RCCL" in line["config"]["gather"]
     assert line["config"]["samples_in_flight"] == [6] and "6 spp" in line["config"]["workload"]
+    # the gather timed alone by a hipEvent pair behind the C ABI (wfpt_gather_accumulated_timed), the rank's own time, the ceiling
+    assert line["gather_ms"] > 0 and line["gather_ms_per_rank"] == [line["gather_ms"]] and "hipEvent" in line["gather_ms_note"]
+    assert len(line["rank_ms_per_step"]) == 1 and len(line["rank_render_ms_per_step"]) == 1 and line["value_per_rank_ceiling"] > 0
+    assert line["config"]["loop_kind"] == "fused"  # 400x225 pixel-keyed: below the binned loop's size gate, and the line says what really ran
 
 
 def test_bench_starts_its_own_ranks(gpu):

@@ -103,10 +103,14 @@ CASES = [
 @pytest.mark.parametrize("kind,w,h,spp,bounces", CASES)
 @pytest.mark.parametrize("rng_mode", [0, 1])
 # fused bounce launches: hipGraph replay / direct; 4 = WFPT_FLAG_UNFUSED: stage kernels one by one; 128 = WFPT_FLAG_NO_BINNING (the pixel-keyed mode's
-# default is the class-binned loop), 256 = WFPT_FLAG_BINNING (the class-binned loop in the dispatch-keyed mode too, thread indices carried)
+# default is the class-binned loop), 256 = WFPT_FLAG_BINNING (the class-binned loop whatever the size of the slab; pixel-keyed mode only)
 @pytest.mark.parametrize("flags", [0, 2, 4, 6, 128, 256, 258])
 def test_device_resident_loop(gpu, orc, kind, w, h, spp, bounces, rng_mode, flags):
     W = gpu
+    if (flags & W.FLAG_BINNING) and rng_mode != W.RNG_PIXEL:
+        with pytest.raises(W.WfptError):  # the class-binned loop gives up the queue's order, which shade.wgsl:72's RNG key needs
+            make_tracer(W, kind, w, h, rng_mode=rng_mode, max_wavefronts=bounces, flags=flags)
+        return
     o = make_oracle(orc, inputs_for(orc, kind, w, h), w, h, rng_mode=rng_mode, max_wavefronts=bounces)
     pt = make_tracer(W, kind, w, h, rng_mode=rng_mode, max_wavefronts=bounces, flags=flags)
     for s in range(spp):
@@ -253,6 +257,8 @@ def test_full_hd_against_golden(gpu, mode, config):
     w, h, spp, bounces = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["bounces"])
     flags = {"config2": 0, "config4-split-shade": W.FLAG_SPLIT_SHADE, "unfused": W.FLAG_UNFUSED,
              "binned": W.FLAG_BINNING, "not-binned": W.FLAG_NO_BINNING}[config]
+    if config == "binned" and mode != W.RNG_PIXEL:
+        pytest.skip("the class-binned loop exists in the pixel-keyed RNG mode only")
     pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, rng_mode=mode, flags=flags)
     for s in range(spp):
         pt.render_sample()
@@ -316,10 +322,21 @@ def test_many_samples_in_flight(gpu, orc):
     spp = 128 + 37
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    for batch, flags in ((128, 0), (100, W.FLAG_NO_GRAPH), (500, 0), (128, W.FLAG_UNFUSED), (128, W.FLAG_BINNING), (100, W.FLAG_BINNING | W.FLAG_NO_GRAPH)):
+    for batch, flags in ((128, 0), (100, W.FLAG_NO_GRAPH), (500, 0), (128, W.FLAG_UNFUSED)):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")
+        assert np.array_equal(pt.totals(), o.totals())
+        pt.close()
+    o.close()
+    # the class-binned loop (pixel-keyed RNG) with 128 samples in flight: its plan holds 128 x kBinClasses (sample, class) entries
+    o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces, rng_mode=W.RNG_PIXEL)
+    want = o.render(spp)
+    for batch, flags in ((128, W.FLAG_BINNING), (100, W.FLAG_BINNING | W.FLAG_NO_GRAPH)):
+        pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags, rng_mode=W.RNG_PIXEL)
+        assert pt.loop_kind == "fused_binned"
+        pt.render(spp)
+        assert_bit_equal(pt.accumulated(), want, f"binned, batch={batch} flags={flags}")
         assert np.array_equal(pt.totals(), o.totals())
         pt.close()
     o.close()
@@ -333,8 +350,7 @@ def test_batched_samples_equal_sequential(gpu, orc, batch):
     w, h, spp, bounces = 200, 120, 19, 5  # 19 = full batches plus a remainder rendered one by one
     o = make_oracle(orc, inputs_for(orc, "shirley", w, h), w, h, max_wavefronts=bounces)
     want = o.render(spp)
-    # (WFPT_FLAG_TWO_CHAINS: the batch's halves as two chains of launches on two streams; with and without a captured graph)
-    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED, W.FLAG_BINNING, W.FLAG_TWO_CHAINS, W.FLAG_TWO_CHAINS | W.FLAG_NO_GRAPH, W.FLAG_TWO_CHAINS | W.FLAG_BINNING):
+    for flags in (0, W.FLAG_NO_GRAPH, W.FLAG_UNFUSED):
         pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"batch={batch} flags={flags}")

@@ -61,7 +61,7 @@ def test_mesh_device_loop(gpu, orc, n_tris, scale, w, h):
     # binary tree as it is: all four must give the oracle's image
     # (scenes beyond LDS additionally trace with dynamic lane refill by default; WFPT_FLAG_NO_REFILL = the fused bounce kernel)
     for batch, flags in ((1, 0), (4, 0), (4, W.FLAG_NO_REFILL), (4, W.FLAG_BINARY_BVH), (4, W.FLAG_UNFUSED),
-                         (2, W.FLAG_UNFUSED | W.FLAG_BINARY_BVH), (4, W.FLAG_TWO_CHAINS), (5, W.FLAG_TWO_CHAINS | W.FLAG_NO_REFILL)):
+                         (2, W.FLAG_UNFUSED | W.FLAG_BINARY_BVH), (5, W.FLAG_NO_REFILL)):
         pt = make_mesh_tracer(W, w, h, n_tris, scale, max_wavefronts=bounces, batch=batch, flags=flags)
         pt.render(spp)
         assert_bit_equal(pt.accumulated(), want, f"mesh image, batch {batch}, flags {flags}")

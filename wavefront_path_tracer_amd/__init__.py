@@ -24,7 +24,7 @@ from . import _build
 
 __all__ = ["SPP", "SPF", "Scene", "BVHTree", "Camera", "CameraController", "ProjectionMatrix", "GPUFrameBuffer",
            "RenderParameters", "RenderProgress", "Kernel", "PathTracer", "WfptError", "workgroup_size_64",
-           "RNG_DISPATCH", "RNG_PIXEL", "FLAG_SPLIT_SHADE", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "FLAG_BINARY_BVH", "FLAG_NO_REFILL", "FLAG_NO_LDS_SCENE", "FLAG_EXACT_TRAVERSAL", "FLAG_NO_BINNING", "FLAG_BINNING", "FLAG_TWO_CHAINS", "STAGES", "lib", "build",
+           "RNG_DISPATCH", "RNG_PIXEL", "FLAG_SPLIT_SHADE", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "FLAG_BINARY_BVH", "FLAG_NO_REFILL", "FLAG_NO_LDS_SCENE", "FLAG_EXACT_TRAVERSAL", "FLAG_NO_BINNING", "FLAG_BINNING", "STAGES", "lib", "build",
            "tonemap_rgb8", "selftest_math", "device_count"]
 
 SPP = 10  # wavefront_common/src/parameters.rs:4
@@ -32,7 +32,7 @@ SPF = 1   # wavefront_common/src/parameters.rs:5
 
 RNG_DISPATCH, RNG_PIXEL = 0, 1
 LOOP_KINDS = ("stages", "fused", "fused_binned", "refill")  # wfpt_loop_kind
-FLAG_SPLIT_SHADE, FLAG_NO_GRAPH, FLAG_UNFUSED, FLAG_BINARY_BVH, FLAG_NO_REFILL, FLAG_NO_LDS_SCENE, FLAG_EXACT_TRAVERSAL, FLAG_NO_BINNING, FLAG_BINNING, FLAG_TWO_CHAINS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+FLAG_SPLIT_SHADE, FLAG_NO_GRAPH, FLAG_UNFUSED, FLAG_BINARY_BVH, FLAG_NO_REFILL, FLAG_NO_LDS_SCENE, FLAG_EXACT_TRAVERSAL, FLAG_NO_BINNING, FLAG_BINNING = 1, 2, 4, 8, 16, 32, 64, 128, 256
 INACTIVE_PIXEL = 0xFFFFFFFF
 # kernel.rs:32 loads shaders/{name}.wgsl; these are the stage names (path_tracer.rs:162,167,175,180,185)
 STAGES = {"generate_rays": 0, "extend": 1, "shade": 2, "miss_kernel": 3, "accumulate": 4,

@@ -76,17 +76,10 @@ struct wfpt_ctx {
     uint32_t *f_chunk_hits[2] = {nullptr, nullptr}, *f_chunk_miss[2] = {nullptr, nullptr}, *first_seg = nullptr;
     // class-binned fused loop (LDS-resident scenes; bounce_binned_kernel): per-segment class totals, the scan's per-class tables, the
     // work-item plan, and -- dispatch-keyed RNG -- extend's hit flags per thread index with the rank table made of them
-    bool bin_capable = false;     // buffers exist (decided at wfpt_create: fused loop, sizes within the record packing, flag clear)
+    bool bin_capable = false;     // buffers exist (decided at wfpt_create: fused loop, pixel-keyed RNG, sizes within the record packing, flag clear)
     uint32_t *f_cls[2] = {nullptr, nullptr}, *first_seg_cls = nullptr, *plan = nullptr;
     uint2 *cls_table = nullptr;
-    uint8_t *hit_flags = nullptr;
-    uint4 *rank_table = nullptr;
     uint32_t bounce_binned_blocks_per_cu = 1;
-    // two chains: the fused loop's batch runs as two halves on two streams, so that the tail of one half's launch
-    // (a handful of long rays) overlaps with the bulk of the other's
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    size_t spill_words = 0; // words of one chain's stack-spill area (HBM-resident scenes)
     // multi-GPU gather of the band-sharded frame (RCCL over xGMI)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -262,7 +255,7 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.scene = c->scene;
     return a;
 }
-// `first`: the chain's first sample (two chains: the per-sample arrays of a chain start `first` slices in)
+// `first`: the first sample of the launch's slices (0: a batch is one chain of launches)
 ScanArgs scan_args(wfpt_ctx *c, const uint32_t *n_in, uint32_t limit, bool fused, uint32_t bounce, uint32_t nb = 1, int fused_parity = -1, uint32_t first = 0) {
     ScanArgs a{};
     a.batch = batch_of(c, nb);
@@ -333,7 +326,7 @@ AccumulateArgs accumulate_args(wfpt_ctx *c, uint32_t n_pixels, bool bookkeeping,
     return a;
 }
 
-constexpr uint32_t kPlanWords = kMaxBatch * (kBinClasses + 2) + 8; // work-item plan of the class-binned loop, one per chain
+constexpr uint32_t kPlanWords = kMaxBatch * (kBinClasses + 2) + 8; // work-item plan of the class-binned loop
 BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb, uint32_t first = 0) {
     BounceArgs a{};
     a.batch = batch_of(c, nb);
@@ -351,14 +344,12 @@ BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb, 
     a.mq_out = c->f_mq[out_parity]; a.mq_out.base += qo;
     if (c->bin_capable) {
         constexpr size_t kWords = ClsPack<kBinClasses>::kWords;
-        a.plan = c->plan + (first ? kPlanWords : 0u);
+        a.plan = c->plan;
         a.plan_seg_off = nb * kBinClasses + 1u;
         a.plan_miss_off = a.plan_seg_off + nb + 1u;
         a.cls_table = c->cls_table + co * kBinClasses;
         a.first_seg_cls = c->first_seg_cls + co * kBinClasses;
         a.out_cls = c->f_cls[out_parity] + co * kWords;
-        a.rank_in = c->rank_table + qo / 64;
-        a.flag_out = c->hit_flags + qo;
     }
     a.image = c->image + static_cast<size_t>(first) * c->image_floats;
     a.ctl = c->ctl + first;
@@ -370,7 +361,6 @@ BounceArgs bounce_args(wfpt_ctx *c, int in_parity, int out_parity, uint32_t nb, 
     a.image_width = c->width;
     a.tile = c->tile;
     a.scene = c->scene;
-    if (first && a.scene.stack_spill) a.scene.stack_spill += c->spill_words;
     return a;
 }
 RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb, uint32_t first = 0) {
@@ -392,7 +382,6 @@ RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb, uint32_t first =
     a.image_width = c->width;
     a.tile = c->tile;
     a.scene = c->scene;
-    if (first && a.scene.stack_spill) a.scene.stack_spill += c->spill_words; // the second chain's launches run beside the first's: a spill area of their own
     return a;
 }
 CompactArgs compact_args(wfpt_ctx *c, int out_parity, uint32_t nb, uint32_t first = 0) {
@@ -423,15 +412,12 @@ ScanBinnedArgs scan_binned_args(wfpt_ctx *c, uint32_t bounce, uint32_t nb, int p
     ScanBinnedArgs a{};
     a.batch = batch_of(c, nb);
     constexpr size_t kWords = ClsPack<kBinClasses>::kWords;
-    const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
+    const size_t co = static_cast<size_t>(first) * c->n_chunks_max;
     a.chunk_hits = c->f_chunk_hits[parity] + co;
     a.chunk_miss = c->f_chunk_miss[parity] + co;
     a.chunk_cls = c->f_cls[parity] + co * kWords;
     a.cls_table = c->cls_table + co * kBinClasses;
     a.first_seg_cls = c->first_seg_cls + co * kBinClasses;
-    const bool keyed_by_order = c->p.rng_mode != WFPT_RNG_PIXEL;
-    a.flags = keyed_by_order ? c->hit_flags + qo : nullptr;
-    a.rank = keyed_by_order ? c->rank_table + qo / 64 : nullptr;
     a.ctl = c->ctl + first;
     a.n_in = &c->ctl[first].n_in;
     a.limit = c->capacity;
@@ -443,7 +429,7 @@ PlanArgs plan_args(wfpt_ctx *c, uint32_t nb, bool last, uint32_t first = 0) {
     PlanArgs a{};
     a.batch = batch_of(c, nb);
     a.ctl = c->ctl + first;
-    a.plan = c->plan + (first ? kPlanWords : 0u);
+    a.plan = c->plan;
     a.plan_seg_off = nb * kBinClasses + 1u;
     a.plan_miss_off = a.plan_seg_off + nb + 1u;
     a.last = last ? 1u : 0u;
@@ -453,7 +439,7 @@ PlanArgs plan_args(wfpt_ctx *c, uint32_t nb, bool last, uint32_t first = 0) {
 // the record's 16 bits
 bool use_binned(const wfpt_ctx *c) {
     return c->bin_capable && c->fused && c->scene.lds_scene && !c->rec_dense && c->scene.n_spheres <= (1u << 16) &&
-           c->batch_max * static_cast<uint32_t>(kBinClasses) <= 512u;
+           c->batch_max * static_cast<uint32_t>(kBinClasses) <= 1024u && c->p.rng_mode == WFPT_RNG_PIXEL;
 }
 uint32_t bounce_grid(const wfpt_ctx *c, uint32_t n) {
     // hit items + miss items never exceed 1.25 work items per segment
@@ -461,7 +447,6 @@ uint32_t bounce_grid(const wfpt_ctx *c, uint32_t n) {
     return static_cast<uint32_t>(std::min<uint64_t>(items, static_cast<uint64_t>(c->cus) * c->bounce_blocks_per_cu));
 }
 
-constexpr uint32_t kChainMinSamples = 2; // a batch of at least twice this many samples runs as two chains
 // One batch of fused samples on the stream (pt:291-368). `ev`: optional (stage, start, stop) event recorder.
 struct EventRec { int stage; hipEvent_t start, stop; };
 
@@ -549,21 +534,7 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
     c->cur = 0;
     const bool split = (c->p.flags & WFPT_FLAG_SPLIT_SHADE) != 0;
     if (c->fused) {
-        // Two chains (WFPT_FLAG_TWO_CHAINS, an experiment kept for measurement): a launch of the fused loop ends on its longest rays -- a
-        // tail in which most of the chip idles. The batch's samples are independent, so its two halves can run as two chains on two
-        // streams (two branches of the captured graph): while one half's launch drains, the other half's fills the chip. Measured: slower
-        // at every slab size (the halves' launches pay the per-launch costs twice and do not overlap the way the picture suggests).
-        // The event-timed pass (wfpt_render_timed) always runs one chain.
-        const uint32_t n1 = (!ev && c->stream2 && nb >= 2u * kChainMinSamples && (c->p.flags & WFPT_FLAG_TWO_CHAINS)) ? nb / 2u : 0u;
-        if (n1) {
-            WFPT_HIP(c, hipEventRecord(c->ev_fork, c->stream));
-            WFPT_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            WFPT_HIP(c, launch_chain_head(c->ctl, nb - n1, c->stream2)); // frame uniform and ticket of the second chain's first Control block
-            if (int r = enqueue_fused_chain(c, timed, n1, nb - n1, c->stream2); r != WFPT_OK) return r;
-            WFPT_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-        }
-        if (int r = enqueue_fused_chain(c, timed, nb - n1, 0, c->stream); r != WFPT_OK) return r;
-        if (n1) WFPT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (int r = enqueue_fused_chain(c, timed, nb, 0, c->stream); r != WFPT_OK) return r;
         WFPT_HIP(c, timed(WFPT_STAGE_ACCUMULATE, [&] {
                      return launch_accumulate(accumulate_args(c, c->n_pixels, true, nb), c->accumulate_grid, c->stream);
                  }));
@@ -981,8 +952,7 @@ int upload_scene(wfpt_ctx *c, const wfpt_sphere *spheres, const wfpt_triangle *t
         const uint32_t need = 3u * (c->depth4 + 1u);
         const uint32_t spill_entries = need > kStack4Lds ? need - kStack4Lds : 1u;
         c->scene.spill_stride = c->cus * std::max(c->blocks_per_cu, c->bounce_blocks_per_cu) * static_cast<uint32_t>(kExtendThreads);
-        c->spill_words = static_cast<size_t>(spill_entries) * c->scene.spill_stride;
-        WFPT_HIP(c, dmalloc(&c->d_stack_spill, 2 * c->spill_words)); // one area per chain (enqueue_batch)
+        WFPT_HIP(c, dmalloc(&c->d_stack_spill, static_cast<size_t>(spill_entries) * c->scene.spill_stride));
         c->scene.stack_spill = c->d_stack_spill;
     }
     return WFPT_OK;
@@ -1063,6 +1033,11 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: null or empty argument");
         return nullptr;
     }
+    if ((params->flags & WFPT_FLAG_BINNING) != 0 && params->rng_mode != WFPT_RNG_PIXEL) {
+        fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: WFPT_FLAG_BINNING needs WFPT_RNG_PIXEL (the class-binned loop reorders the hit queue, which "
+                                                 "shade.wgsl:72's RNG key, the dispatch's thread index, does not allow)");
+        return nullptr;
+    }
     if (params->max_wavefronts == 0 || params->max_wavefronts > static_cast<uint32_t>(kMaxRows)) {
         fail(nullptr, WFPT_ERR_INVALID_ARGUMENT, "wfpt_create: max_wavefronts must be in 1..64");
         return nullptr;
@@ -1112,9 +1087,6 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
 
     CREATE_HIP(hipSetDevice(c->device));
     CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    CREATE_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    CREATE_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     set_viewport(c, params->width, params->height);
     c->pixel_capacity = std::max(c->n_pixels, c->tile.world <= 1 ? params->max_pixels : 0u);
     // ray slots: whole tiles (partial tiles carry padding lanes), rounded up to whole segments
@@ -1124,18 +1096,15 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     cap = (cap + kChunk - 1) / kChunk * kChunk;
     if (cap == 0) cap = kChunk;
     // The class-binned loop cuts every class's hits into work items of kChunk, so a wavefront may fill up to kBinClasses - 1 more
-    // (partly filled) segments than its rays would: room for them. Its records pack a thread index of kBinPixelBits bits beside the
-    // pixel index, so both must stay below 2^23 (3840x2160 does); larger contexts keep the thread-ordered queue.
-    // (default in the pixel-keyed RNG mode, where the order of the queue is free; on request in the dispatch-keyed mode, where carrying the
-    // reference's order through the binning costs what the binning gains: include/wfpt.h, WFPT_FLAG_BINNING)
+    // (partly filled) segments than its rays would: room for them. WFPT_RNG_PIXEL only: the order of the queue is free there
+    // (include/wfpt.h, WFPT_FLAG_BINNING).
     // A small slab gains nothing: every class of every sample ends on a partly filled work item, and the late wavefronts of 1/4 or 1/8
     // of a 1920x1080 frame are a handful of work items per sample (measured per rank of N = 1 / 2 / 4 / 8, 64 samples in flight:
     // 18.53 / 9.77 / 5.28 / 3.08 ms binned against 19.08 / 9.85 / 5.14 / 2.90 in thread order), so the default asks for 3/4 Mpixel.
     const bool auto_on = params->rng_mode == WFPT_RNG_PIXEL && (params->flags & WFPT_FLAG_NO_BINNING) == 0 && c->n_pixels >= (3u << 18);
     const bool want_binning = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE | WFPT_FLAG_NO_LDS_SCENE)) == 0 &&
-                              (auto_on || (params->flags & WFPT_FLAG_BINNING) != 0);
-    if (want_binning && cap + kBinClasses * kChunk <= (1ull << 23) && c->pixel_capacity <= (1u << 23) &&
-        static_cast<uint64_t>(params->width) * params->height <= (1ull << 23)) {
+                              params->rng_mode == WFPT_RNG_PIXEL && (auto_on || (params->flags & WFPT_FLAG_BINNING) != 0);
+    if (want_binning && cap + kBinClasses * kChunk <= 0xffffffffull) {
         cap += kBinClasses * kChunk;
         c->bin_capable = true;
     }
@@ -1210,12 +1179,8 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
             CREATE_HIP(hipMemsetAsync(c->cls_table, 0, sizeof(uint2) * counts * kBinClasses, c->stream));
             CREATE_HIP(dmalloc(&c->first_seg_cls, counts * kBinClasses));
             CREATE_HIP(hipMemsetAsync(c->first_seg_cls, 0, sizeof(uint32_t) * counts * kBinClasses, c->stream));
-            CREATE_HIP(dmalloc(&c->plan, 2 * kPlanWords));
-            CREATE_HIP(hipMemsetAsync(c->plan, 0, sizeof(uint32_t) * 2 * kPlanWords, c->stream));
-            CREATE_HIP(dmalloc(&c->hit_flags, slots));
-            CREATE_HIP(hipMemsetAsync(c->hit_flags, 0, slots, c->stream));
-            CREATE_HIP(dmalloc(&c->rank_table, slots / 64));
-            CREATE_HIP(hipMemsetAsync(c->rank_table, 0, sizeof(uint4) * (slots / 64), c->stream));
+            CREATE_HIP(dmalloc(&c->plan, kPlanWords));
+            CREATE_HIP(hipMemsetAsync(c->plan, 0, sizeof(uint32_t) * kPlanWords, c->stream));
         }
     }
     CREATE_HIP(hipMemsetAsync(c->accumulated, 0, sizeof(float) * c->acc_floats, c->stream));         // pt:60-65
@@ -1346,15 +1311,11 @@ void wfpt_destroy(wfpt_ctx *c) {
     free_scene(c);
     void *bufs[] = {c->rec_dense, c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
                     c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg, c->f_cls[0], c->f_cls[1], c->first_seg_cls, c->plan, c->cls_table,
-                    c->hit_flags, c->rank_table,
                     c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -240,20 +240,14 @@ struct BounceArgs {
     uint32_t image_width;
     Tiling tile;
     SceneDev scene;
-    // ---- class-binned loop (bounce_binned_kernel): the hits of a segment are stored sorted by COST CLASS (ShadeRec::cost_class of the
-    // primitive hit), and a work item of the next launch is kChunk hits of ONE class (of one sample), found through the per-class tables
-    // the scan leaves. The PHYSICAL order of the queue is then no longer the reference's thread order, which shade's RNG is keyed by
-    // in WFPT_RNG_DISPATCH (sh:72). The logical order is carried instead: every ray has its thread index t of the reference's extend
-    // dispatch; extend leaves one flag byte per t (hit or not); the scan turns the flags into a rank table (per 64 thread indices: hits
-    // before them + the 64 hit bits); a hit record carries the t of the ray that made it, and the next launch recovers shade's thread
-    // index h = hits with a smaller t = prefix + popcount -- exactly the queue position ascending-order atomics (ex:59) give the hit.
+    // ---- class-binned loop (bounce_binned_kernel; WFPT_RNG_PIXEL only, where the order of the queue is free): the hits of a segment are
+    // stored sorted by COST CLASS (ShadeRec::cost_class of the primitive hit), and a work item of the next launch is kChunk hits of ONE
+    // class (of one sample), found through the per-class tables the scan leaves.
     const uint32_t *plan;           // [n * K + 1] first hit item of each (sample, class) | [n + 1] first segment item of each sample | [n + 1] first miss item
     uint32_t plan_seg_off, plan_miss_off;
     const uint2 *cls_table;         // in:  [n][segments][K] {class-k hits before this segment, first slot of the segment's class-k run}
     const uint32_t *first_seg_cls;  // in:  [n][K][segments]: segment that holds class-k hit number kChunk * run
     uint32_t *out_cls;              // out: [n][segments][words] per-segment class totals, packed 10 bits each (ClsPack)
-    const uint4 *rank_in;           // in (WFPT_RNG_DISPATCH): [n][capacity / 64] {hit bits 0-31, 32-63, hits before this group, -} of the previous extend
-    uint8_t *flag_out;              // out (WFPT_RNG_DISPATCH): [n][capacity] 1 = the ray with this thread index hit
 };
 
 // Packed counters of the class-binned compaction: field f of a word array sits in word f / 3 at bit 10 * (f % 3); a field holds at most
@@ -261,7 +255,7 @@ struct BounceArgs {
 template <int K> struct ClsPack {
     static constexpr int kFields = K + 2, kWords = (kFields + 2) / 3;
 };
-constexpr int kBinClasses = 4; // classes of the binned loop as built: 0 = the dominant primitive (the Shirley scene's ground), 1 + material type otherwise
+constexpr int kBinClasses = 4; // classes of the binned loop: 0 = the dominant primitive (the Shirley scene's ground), 1 + material type otherwise
 static_assert(kBinClasses <= kClsMax && kChunk <= 1023, "a packed field must hold a segment's count");
 
 struct ScanBinnedArgs {
@@ -269,8 +263,6 @@ struct ScanBinnedArgs {
     const uint32_t *chunk_hits, *chunk_miss, *chunk_cls; // per-segment totals of this wavefront (chunk_cls: ClsPack words)
     uint2 *cls_table;
     uint32_t *first_seg_cls;
-    const uint8_t *flags; // WFPT_RNG_DISPATCH: hit flag per thread index of this wavefront's extend (null: pixel-keyed RNG, the order is free)
-    uint4 *rank;          // ... and the rank table made of them
     Control *ctl;
     const uint32_t *n_in;
     uint32_t limit, miss_floor, bounce;
@@ -402,8 +394,6 @@ hipError_t launch_miss(const MissArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t s);
 hipError_t launch_fill(float *p, float v, size_t n, hipStream_t s);
 hipError_t launch_set_frame(Control *ctl, const wfpt_frame_buffer &f, hipStream_t s); // ctl->frame = f, ordered on the stream
-// second chain of a batch: ctl[first] gets the frame uniform of sample `first` (ctl[0]'s, frame + first) and a fresh ticket
-hipError_t launch_chain_head(Control *ctl, uint32_t first, hipStream_t s);
 // frame band (j * world + rank) <- slab band j for the first n_valid floats of a slab: the root of the multi-GPU gather
 hipError_t launch_band_scatter(float *frame, const float *slab, size_t n_valid, size_t band_floats, uint32_t world, uint32_t rank, hipStream_t s);
 // AoS <-> SoA converters for the read-back / injection paths

@@ -1919,20 +1919,21 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
 }
 
 // ================================================================================================
-// Class-binned fused loop (round 4; LDS-resident scenes). bounce_kernel takes 512 CONSECUTIVE hits per work item, so
-// a wave holds rays that leave the ground next to rays that leave a marble, and lambertian next to dielectric hits: its while-while
-// traversal runs at 0.49 / 0.40 / 0.36 lane utilisation at bounces 1-3 and every wave runs every material branch of shade. Here the
-// hits of a segment are stored sorted by the COST CLASS of the primitive hit (ShadeRec::cost_class: 0 = the scene's dominant primitive,
-// 1 + material type otherwise; tests/model_binning.py scores the keys) -- K ballots instead of one, counts exchanged as packed 10-bit
-// fields, no atomics on the queues and nothing exchanged inside a work item; the scan leaves, per class, the running count in front of
-// every segment, and a work item of the next launch is 512 hits of ONE class of one sample.
-// The reference's ORDER survives although the storage loses it (BounceArgs::plan ff.): every ray knows its thread index t of the
-// reference's extend dispatch; extend leaves a hit flag per t; a hit record carries t (23 bits, packed above the pixel and primitive
-// indices); the scan turns the flags into the rank table and the next launch shades the record as the reference's shade thread
-// h = (hits with a smaller t), whose extension ray is extend thread h (sh:155 under ascending-order atomics). In WFPT_RNG_PIXEL nothing
-// depends on the order and the flags / rank table are skipped.
+// Class-binned fused loop (round 4; LDS-resident scenes, WFPT_RNG_PIXEL, where the order of the hit queue is free).
+// bounce_kernel takes 512 CONSECUTIVE hits per work item, so a wave holds rays that leave the ground next to rays that leave a marble, and
+// lambertian next to dielectric hits: its while-while traversal runs at 0.49 / 0.40 / 0.36 lane utilisation at bounces 1-3 and every wave
+// runs every material branch of shade. Here the hits of a segment are stored sorted by the COST CLASS of the primitive hit
+// (ShadeRec::cost_class: 0 = the scene's dominant primitive, 1 + material type otherwise; tests/model_binning.py scores the keys) -- K
+// ballots instead of one, counts exchanged as packed 10-bit fields, no atomics on the queues and nothing exchanged inside a work item; the
+// scan leaves, per class, the running count in front of every segment, and a work item of the next launch is 512 hits of ONE class of one
+// sample.
+// Round 4 also carried the reference's ORDER through the binning for WFPT_RNG_DISPATCH (thread indices in the records, a hit flag per ray, a
+// rank table per wavefront): 5.8 % slower than the thread-ordered loop, removed in round 5. Round 5 built the key that the gate model scores
+// best -- (dominant | rest) x the direction.y the extension ray WILL have, computed at write time from the path's rb.y (constant per path in
+// this RNG mode: it rode above the pixel index as an 8-bit snorm) with rcp / rsq arithmetic, 8 classes -- and measured it: lanes per VALU
+// instruction 32.8 -> 34.8 and 8 % fewer visits, as tests/model_dirkey.py predicts, but the launch 6 % SLOWER (23 % more record loads of
+// sparser classes, the key's own instructions, the first launch's rb.y): not kept; profiles/r05_rejected_experiments.txt.
 // ================================================================================================
-constexpr uint32_t kBinPixelBits = 23, kBinPrimBits = 16; // record words: pixel | t[0:9) << 23, primitive | t[9:23) << 16
 template <int K> __device__ __forceinline__ uint32_t cls_field(const uint32_t *w, int f) { return (w[f / 3] >> (10 * (f % 3))) & 1023u; }
 
 template <int MODE, typename Trail, int PRIM, bool EXACT, int K>
@@ -1948,7 +1949,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_geom + geom_words);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geom + geom_words + parent_words); // [2][kExtendWaves][NW] packed per-wave counts
     uint32_t *s_next = s_cnt + 2 * kExtendWaves * NW;                                    // [2] next work item
-    uint8_t *s_cls = reinterpret_cast<uint8_t *>(s_next + 2);                            // [n_prims] cost class of each primitive (ShadeRec::cost_class)
+    uint8_t *s_cls = reinterpret_cast<uint8_t *>(s_next + 2);                            // [n_prims] ShadeRec::cost_class of each primitive
 
     const uint32_t nb = a.batch.n;
     const uint32_t n_slots = a.gx * a.gy * 64u; // first wavefront: ray slots of this context's tiles
@@ -1978,7 +1979,6 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     wfpt_frame_buffer fb0 = a.ctl->frame; // the same for every lane: kept in scalar registers
     fb0.width = uniform(fb0.width); fb0.height = uniform(fb0.height); fb0.frame = uniform(fb0.frame); fb0.sample_number = uniform(fb0.sample_number);
     const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6);
-    const bool keyed_by_order = a.rng_mode != WFPT_RNG_PIXEL; // the reference's RNG key: thread indices are carried, flags written
     uint32_t idx_h = 0, idx_m = 0; // a workgroup's tickets only grow: the plan is searched on from where the previous item was found
     uint32_t iter = 0;
     while (item < n_items) {
@@ -2019,7 +2019,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         uint32_t smp, seg_out;
         bool live;
         float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-        uint32_t pixel_idx = 0, tidx = 0; // tidx: this ray's thread index in the reference's extend dispatch of this wavefront
+        uint32_t pixel_idx = 0;
         if (MODE == kBounceFirst) {
             smp = item / items_first;
             seg_out = item - smp * items_first;
@@ -2044,8 +2044,6 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             const uint32_t id_x = wx * 8u + (local_index & 7u);
             const uint32_t id_y = (wy * a.tile.world + a.tile.rank) * 8u + (local_index >> 3);
             live = h < n_first && id_x < fb.width && id_y < fb.height;
-            tidx = h;
-            if (keyed_by_order && h < n_first && !live) a.flag_out[qo + h] = 0; // an inactive slot is a thread index without a hit
             if (live) {
                 pixel_idx = id_x + id_y * fb.width; // gr:57
                 const PrimaryRay pr = primary_ray(*a.camera, id_x, id_y, fb.width, fb.height, fb);
@@ -2082,22 +2080,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 slot = qo + static_cast<size_t>(seg_out) * kChunk + threadIdx.x;
             }
             if (live) {
-                float4 ra = a.rec_in[2u * slot];
-                const float4 rb = a.rec_in[2u * slot + 1u];
-                const uint32_t wa = __float_as_uint(ra.w), wb = __float_as_uint(rb.w);
-                const uint32_t prim = wb & ((1u << kBinPrimBits) - 1u);
-                ra.w = __uint_as_float(wa & ((1u << kBinPixelBits) - 1u));
-                uint32_t h = 0;
-                if (TRACE && keyed_by_order) { // shade's thread index: hits of the previous extend with a smaller thread index
-                    const uint32_t t_prev = (wa >> kBinPixelBits) | ((wb >> kBinPrimBits) << (32u - kBinPixelBits));
-                    const uint4 g = a.rank_in[(qo >> 6) + (t_prev >> 6)];
-                    const uint32_t bit = t_prev & 63u;
-                    const uint32_t below_lo = bit >= 32u ? g.x : (g.x & ((1u << bit) - 1u));
-                    const uint32_t below_hi = bit > 32u ? (g.y & ((1u << (bit - 32u)) - 1u)) : 0u;
-                    h = g.z + static_cast<uint32_t>(__popc(below_lo)) + static_cast<uint32_t>(__popc(below_hi));
-                }
-                tidx = h; // shade thread h writes extension ray h (sh:155): extend's thread index
-                shade_record<TRACE, true, false>(src, ra, rb, prim, h, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
+                const float4 ra = a.rec_in[2u * slot], rb = a.rec_in[2u * slot + 1u];
+                shade_record<TRACE, true, false>(src, ra, rb, __float_as_uint(rb.w), 0u, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
             }
         }
         if (!TRACE) {
@@ -2126,9 +2110,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         }
         const bool miss = live && !hit;
         // ---------------- compaction, class by class: K ballots, per-wave counts as packed fields, one LDS exchange
+        const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz; // the hit point shade will read: p = origin + t * direction (sh:91)
         uint32_t cls = K; // no hit
         if (hit) cls = s_cls[prim]; // ShadeRec::cost_class
-        if (keyed_by_order && live) a.flag_out[qo + tidx] = hit ? 1 : 0;
         const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
         uint32_t wcnt[NW];
 #pragma unroll
@@ -2170,15 +2154,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
             run_off += cls_field<K>(total, k);
         }
         const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
-        if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel -- and the thread index
+        if (hit) { // the path record shade will read: hit point, incoming direction, primitive, pixel
             const uint32_t wsel = cls / 3u, sh = 10u * (cls - 3u * wsel);
             uint32_t wb = before[0], wc = coff[0];
 #pragma unroll
             for (int j = 1; j < NW; ++j) { wb = wsel == static_cast<uint32_t>(j) ? before[j] : wb; wc = wsel == static_cast<uint32_t>(j) ? coff[j] : wc; }
             const size_t slot = seg + ((wc >> sh) & 1023u) + ((wb >> sh) & 1023u) + rank;
-            const uint32_t tt = keyed_by_order ? tidx : 0u;
-            a.rec_out[2u * slot] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(pixel_idx | (tt << kBinPixelBits)));
-            a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim | ((tt >> (32u - kBinPixelBits)) << kBinPrimBits)));
+            a.rec_out[2u * slot] = make_float4(hx, hy, hz, __uint_as_float(pixel_idx));
+            a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
         }
         if (miss) { // what miss_kernel reads of the ray (mk:29-32)
             const size_t slot = seg + cls_field<K>(before, K) + mbcnt(miss_mask);
@@ -2197,8 +2180,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
 }
 
 // ---- scan of the class-binned loop: one workgroup per sample. Per class the running count in front of every segment (and where the
-// class's run starts inside the segment), the segment that holds the first hit of every run of kChunk hits of a class, the counter
-// protocol and loop exit of scan_kernel (pt:327-353), and -- dispatch-keyed RNG -- the rank table made of extend's hit flags.
+// class's run starts inside the segment), the segment that holds the first hit of every run of kChunk hits of a class, and the counter
+// protocol and loop exit of scan_kernel (pt:327-353).
 template <int K>
 __global__ __launch_bounds__(kScanThreads) void scan_binned_kernel(ScanBinnedArgs a) {
     constexpr int NW = ClsPack<K>::kWords, NQ = K + 2; // scanned quantities: K classes, all hits, misses
@@ -2214,47 +2197,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_binned_kernel(ScanBinnedArg
     // segments this wavefront's extend wrote: the first one 512 ray slots each, later ones one per hit work item (plan_kernel's count)
     const uint32_t n_chunks = a.bounce == 0 ? (n + kChunk - 1) / kChunk : (n == 0 ? 0u : c->next_segs);
     const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6);
-    // ---- hit flags -> rank table (thread-contiguous chunks of 64-flag groups: count, block prefix, then the groups' own prefixes)
-    if (a.flags && n > 0) {
-        const uint8_t *flags = a.flags + static_cast<size_t>(sample) * a.batch.queue_stride;
-        uint4 *rank = a.rank + (static_cast<size_t>(sample) * a.batch.queue_stride >> 6);
-        const uint32_t n_groups = (n + 63u) / 64u, per = (n_groups + kScanThreads - 1) / kScanThreads;
-        const uint32_t g0 = umin(threadIdx.x * per, n_groups), g1 = umin(g0 + per, n_groups);
-        uint32_t count = 0;
-        for (uint32_t g = g0; g < g1; ++g) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(flags + static_cast<size_t>(g) * 64u);
-            uint32_t bits[2] = {0u, 0u};
-#pragma unroll
-            for (uint32_t v = 0; v < 4; ++v) {
-                uint4 w = p[v];
-                if (g * 64u + v * 16u + 16u > n) { // the queue's tail: flags beyond the last ray are stale
-                    uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-                    for (uint32_t b = 0; b < 16; ++b)
-                        if (g * 64u + v * 16u + b >= n) ww[b >> 2] &= ~(0xffu << (8u * (b & 3u)));
-                    w = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-                }
-                // four flag bytes (0 / 1) of a word -> four bits: ((x & 0x01010101) * 0x10204080) >> 28 (byte k lands on bit 28 + k, no carries)
-                const uint32_t n0 = ((w.x & 0x01010101u) * 0x10204080u) >> 28, n1 = ((w.y & 0x01010101u) * 0x10204080u) >> 28;
-                const uint32_t n2 = ((w.z & 0x01010101u) * 0x10204080u) >> 28, n3 = ((w.w & 0x01010101u) * 0x10204080u) >> 28;
-                bits[v >> 1] |= (n0 | (n1 << 4) | (n2 << 8) | (n3 << 12)) << (16u * (v & 1u));
-            }
-            rank[g] = make_uint4(bits[0], bits[1], 0u, 0u);
-            count += static_cast<uint32_t>(__popc(bits[0])) + static_cast<uint32_t>(__popc(bits[1]));
-        }
-        const uint32_t inc = wave_inclusive_scan(count);
-        if (lane == 63) s_wave[0][wave] = inc;
-        __syncthreads();
-        uint32_t before = inc - count;
-#pragma unroll
-        for (uint32_t w = 0; w < kScanThreads / 64; ++w) before += (w < wave) ? s_wave[0][w] : 0u;
-        for (uint32_t g = g0; g < g1; ++g) { // (this thread's own stores: visible to itself)
-            uint4 e = rank[g];
-            e.z = before;
-            rank[g] = e;
-            before += static_cast<uint32_t>(__popc(e.x)) + static_cast<uint32_t>(__popc(e.y));
-        }
-        __syncthreads();
-    }
     // ---- per-class prefixes over the segments
     uint32_t carry[NQ];
 #pragma unroll
@@ -2359,7 +2301,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_binned_kernel(ScanBinnedArg
 
 // ---- the work-item plan of the next launch of the class-binned loop: exclusive prefixes over (sample, class) hit items, over the
 // samples' segments (the last launch shades whole segments) and over the samples' miss items, which follow the hit items
-__device__ __forceinline__ uint32_t block_exclusive_scan_512(uint32_t v, uint32_t *s_part, uint32_t &total) {
+constexpr uint32_t kPlanThreads = 1024; // >= kMaxBatch * kBinClasses
+static_assert(kMaxBatch * kBinClasses <= static_cast<int>(kPlanThreads), "plan_kernel: one thread per (sample, class)");
+__device__ __forceinline__ uint32_t block_exclusive_scan_plan(uint32_t v, uint32_t *s_part, uint32_t &total) {
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t inc = wave_inclusive_scan(v);
     __syncthreads();
@@ -2367,7 +2311,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_512(uint32_t v, uint32_
     __syncthreads();
     uint32_t before = inc - v;
     total = 0;
-    for (uint32_t w = 0; w < 8; ++w) {
+    for (uint32_t w = 0; w < kPlanThreads / 64u; ++w) {
         const uint32_t x = s_part[w];
         before += (w < wave) ? x : 0u;
         total += x;
@@ -2375,21 +2319,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_512(uint32_t v, uint32_
     return before;
 }
 template <int K>
-__global__ __launch_bounds__(512) void plan_kernel(PlanArgs a) {
-    __shared__ uint32_t s_part[8];
-    const uint32_t t = threadIdx.x, nb = a.batch.n; // nb * K <= 512 (kMaxBatch samples, kBinClasses classes)
+__global__ __launch_bounds__(kPlanThreads) void plan_kernel(PlanArgs a) {
+    __shared__ uint32_t s_part[kPlanThreads / 64u];
+    const uint32_t t = threadIdx.x, nb = a.batch.n; // nb * K <= kPlanThreads (kMaxBatch samples, kBinClasses classes)
     uint32_t total_h = 0, total_s = 0, total_m = 0;
     uint32_t v = 0;
     if (t < nb * K) v = (a.ctl[t / K].cls_n[t % K] + kChunk - 1) / kChunk;
-    const uint32_t ex_h = block_exclusive_scan_512(v, s_part, total_h);
+    const uint32_t ex_h = block_exclusive_scan_plan(v, s_part, total_h);
     if (t < nb * K) a.plan[t] = ex_h;
     if (t == 0) a.plan[nb * K] = total_h;
     v = (t < nb && a.ctl[t].shade_n > 0) ? a.ctl[t].n_segs : 0u;
-    const uint32_t ex_s = block_exclusive_scan_512(v, s_part, total_s);
+    const uint32_t ex_s = block_exclusive_scan_plan(v, s_part, total_s);
     if (t < nb) a.plan[a.plan_seg_off + t] = ex_s;
     if (t == 0) a.plan[a.plan_seg_off + nb] = total_s;
     v = (t < nb && a.ctl[t].miss_n > 0) ? (a.ctl[t].n_segs + kMissSegsPerItem - 1) / kMissSegsPerItem : 0u;
-    const uint32_t ex_m = block_exclusive_scan_512(v, s_part, total_m);
+    const uint32_t ex_m = block_exclusive_scan_plan(v, s_part, total_m);
     const uint32_t first = a.last ? total_s : total_h;
     if (t < nb) a.plan[a.plan_miss_off + t] = first + ex_m;
     if (t == 0) a.plan[a.plan_miss_off + nb] = first + total_m;
@@ -2763,13 +2707,6 @@ __global__ __launch_bounds__(256) void accumulate_kernel(AccumulateArgs a) {
 // the frame uniform of the next sample (pt:296-297), written on the stream: no host synchronisation between frames
 __global__ void set_frame_kernel(Control *ctl, wfpt_frame_buffer f) { ctl->frame = f; }
 
-__global__ void chain_head_kernel(Control *ctl, uint32_t first) {
-    wfpt_frame_buffer f = ctl[0].frame;
-    f.frame += first;
-    ctl[first].frame = f;
-    ctl[first].ticket = 0;
-}
-
 __global__ void fill_kernel(float *p, float v, size_t n) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -2968,7 +2905,7 @@ hipError_t launch_scan_binned(const ScanBinnedArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_plan(const PlanArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(plan_kernel<kBinClasses>, dim3(1), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(plan_kernel<kBinClasses>, dim3(1), dim3(kPlanThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -3051,11 +2988,6 @@ hipError_t launch_accumulate(const AccumulateArgs &a, uint32_t grid, hipStream_t
 
 hipError_t launch_set_frame(Control *ctl, const wfpt_frame_buffer &f, hipStream_t s) {
     hipLaunchKernelGGL(set_frame_kernel, dim3(1), dim3(1), 0, s, ctl, f);
-    return hipGetLastError();
-}
-
-hipError_t launch_chain_head(Control *ctl, uint32_t first, hipStream_t s) {
-    hipLaunchKernelGGL(chain_head_kernel, dim3(1), dim3(1), 0, s, ctl, first);
     return hipGetLastError();
 }
 
