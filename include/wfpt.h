@@ -476,6 +476,8 @@ int wfpt_selftest_math(int device, int op, const float *a, const float *b, float
 int wfpt_debug_extend_blocks_per_cu(int device, uint32_t lds_bytes);
 /* Diagnostic builds only (-DWFPT_STAMPS=1): per-phase shader-cycle sums of the middle bounce launches; zeros otherwise. */
 int wfpt_debug_read_stamps(wfpt_ctx *ctx, uint64_t out[16], int reset);
+/* ... and of the refill traversal's launches (scenes beyond LDS): which = 1 the first launch, 2 the middle launches (0: the call above) */
+int wfpt_debug_read_stamps_ex(wfpt_ctx *ctx, int which, uint64_t out[16], int reset);
 /* Host-side check of the four-wide quantised tree the device walks for scenes beyond LDS (no GPU needed): collapses
  * `nodes` and verifies that every quantised child box encloses the binary node's box and that the two trees have the
  * same leaves. counts = {four-wide nodes, depth, leaf children, inner children}. */

@@ -39,10 +39,11 @@ static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z -
 static inline v3 v3_scale(float s, v3 a) { return v3_make(s * a.x, s * a.y, s * a.z); }
 static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 static inline float v3_length(v3 a) { return orc_sqrt(v3_dot(a, a)); }
-/* WGSL normalize(v): the built-in's accuracy is "inherited from v / length(v)", i.e. 2.5 ULP per component on top of length's;
- * the definition fixed here (round 4) is v * (1 / length(v)) -- ONE correctly rounded division and a correctly rounded product
- * per component, at most 1.5 ULP away from v / length(v) (tests/test_oracle_math.py::test_normalize_accuracy), and what a shader
- * compiler emits for the built-in on most targets. Rounds 1-3 divided each component. */
+/* WGSL normalize(v): the built-in's accuracy is "inherited from v / length(v)", i.e. 2.5 ULP per component on top of length's. The
+ * definition CHOSEN here (round 4; the device states the same one independently, wfpt_device_math.h: normalize3) is v * (1 / length(v)): one
+ * correctly rounded division and three products per vector, at most 1.5 ULP away from v / length(v) per component
+ * (tests/test_oracle_math.py::test_normalize_accuracy), inside WGSL's bound. The reference holds no fixture that pins the built-in's
+ * rounding, so neither this form nor the per-component division of rounds 1-3 is "the reference's": parity of normalize is unpinned. */
 static inline v3 v3_normalize(v3 a) { float inv = 1.0f / v3_length(a); return v3_make(a.x * inv, a.y * inv, a.z * inv); }
 static inline float v4_dot(v4 a, v4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 static inline v4 v4_normalize(v4 a) {

@@ -240,8 +240,9 @@ def test_update_scene_moves_fifty_spheres(gpu, orc, flags):
     restarts at frame 1, and the image equals both a fresh context on the moved scene and the oracle."""
     W = gpu
     fl = getattr(W, "FLAG_" + flags) if flags else 0
+    mode = W.RNG_PIXEL if flags == "BINNING" else W.RNG_DISPATCH  # the class-binned loop exists in the pixel-keyed mode only
     w, h, spp, bounces = 400, 224, 3, 6
-    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, flags=fl)
+    pt = make_tracer(W, "shirley", w, h, max_wavefronts=bounces, flags=fl, rng_mode=mode)
     pt.render(2)
     before = pt.accumulated()
     moved = W.Scene.book_one_final(1)
@@ -258,12 +259,12 @@ def test_update_scene_moves_fifty_spheres(gpu, orc, flags):
     assert_bit_equal(for_update.spheres, sp_o.view(W.SPHERE), "spheres reordered by the device builder like bvh.rs does")
     pt.render(spp)
     cam, ip, vw = orc.shirley_camera(w, h)
-    o = orc.Oracle(w, h, sp_o, moved.materials.view(orc.MATERIAL), nodes_o, cam, ip, vw, max_wavefronts=bounces)
+    o = orc.Oracle(w, h, sp_o, moved.materials.view(orc.MATERIAL), nodes_o, cam, ip, vw, max_wavefronts=bounces, rng_mode=mode)
     want = o.render(spp)
     assert np.array_equal(pt.bounce_table(), o.bounce_table())
     assert_bit_equal(pt.accumulated(), want, "after wfpt_update_scene vs the oracle")
     cc = W.CameraController(W.Camera.book_one_final_camera(), 20.0, 0.6, 10.0, 0.1, 100.0, 4.0, 0.1)
-    fresh = W.PathTracer(for_fresh, W.RenderParameters(cc, (w, h)), max_wavefronts=bounces, flags=fl)
+    fresh = W.PathTracer(for_fresh, W.RenderParameters(cc, (w, h)), max_wavefronts=bounces, flags=fl, rng_mode=mode)
     fresh.render(spp)
     assert_bit_equal(pt.accumulated(), fresh.accumulated(), "after wfpt_update_scene vs a fresh context")
     assert not np.array_equal(before, pt.accumulated())

@@ -2,7 +2,7 @@
 # tools/evidence.sh ROUND  (on the GPU box, from the repo root): every bench line and rocprofv3 pass that DESIGN.md quotes for a round, in one go.
 # Lines land in gpurun_out/<ROUND>_line_<name>.json; profiles in gpurun_out/prof_<tag>_*; condense the latter with profiles/summarize_rocprof.py
 # and copy the lines to profiles/<ROUND>_bench_line_<name>.json.
-rnd=${1:-r04}
+rnd=${1:-r05}
 line() { name=$1; shift
   timeout -k 10 600 python bench.py "$@" > gpurun_out/${rnd}_line_$name.json 2> gpurun_out/${rnd}_line_$name.err || { echo "$name FAILED"; tail -3 gpurun_out/${rnd}_line_$name.err; return 1; }
   python - gpurun_out/${rnd}_line_$name.json $name <<'PY'
@@ -21,6 +21,5 @@ line unfused --unfused --steps 10 --warmup 2 --cpu-seconds 5 &&
 line exact --exact-traversal --steps 10 --warmup 2 --cpu-seconds 5 &&
 line pixel --rng-mode pixel --steps 10 --warmup 2 --cpu-seconds 5 &&
 line pixel_nobin --rng-mode pixel --no-binning --steps 10 --warmup 2 --no-cpu-baseline &&
-line dispatch_binned --binning --steps 10 --warmup 2 --cpu-seconds 5 &&
 line mesh --scene mesh --steps 4 --warmup 1 --cpu-seconds 10 &&
 bash tools/profile.sh ${rnd}s && bash tools/profile.sh ${rnd}sp --rng-mode pixel && bash tools/profile_mesh.sh ${rnd}m

@@ -272,6 +272,7 @@ def lib():
         "wfpt_write_png_rgb8": (i32, [C.c_char_p, vp, u32, u32]),
         "wfpt_debug_extend_blocks_per_cu": (i32, [i32, u32]),
         "wfpt_debug_read_stamps": (i32, [vp, vp, i32]),
+        "wfpt_debug_read_stamps_ex": (i32, [vp, i32, vp, i32]),
         "wfpt_debug_bvh4": (i32, [vp, u32, vp]),
     }
     for name, (res, args) in sig.items():
@@ -885,7 +886,7 @@ class PathTracer:
 
     def gather_accumulated_timed(self):
         """The same gather, blocking; returns its duration on this rank in milliseconds (hipEvents on the context's stream)."""
-        ms = f32(0.0)
+        ms = C.c_float(0.0)
         self._check(lib().wfpt_gather_accumulated_timed(self.handle, C.byref(ms)))
         return float(ms.value)
 

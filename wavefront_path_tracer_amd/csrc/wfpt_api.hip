@@ -367,6 +367,7 @@ RefillArgs refill_args(wfpt_ctx *c, int in_parity, uint32_t nb, uint32_t first =
     RefillArgs a{};
     a.batch = batch_of(c, nb);
     const size_t co = static_cast<size_t>(first) * c->n_chunks_max, qo = static_cast<size_t>(first) * c->capacity;
+    a.stamps = c->d_stamps;
     a.rec_in = c->rec_mem[in_parity] + 2 * qo;
     a.dense_out = c->rec_dense + 2 * qo;
     a.in_hits = c->f_chunk_hits[in_parity] + co;
@@ -1187,8 +1188,8 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     CREATE_HIP(dmalloc(&c->ctl, kMaxBatch));
     CREATE_HIP(hipMemsetAsync(c->ctl, 0, sizeof(Control) * kMaxBatch, c->stream));
     CREATE_HIP(dmalloc(&c->camera, 1));
-    CREATE_HIP(dmalloc(&c->d_stamps, 16));
-    CREATE_HIP(hipMemsetAsync(c->d_stamps, 0, sizeof(unsigned long long) * 16, c->stream));
+    CREATE_HIP(dmalloc(&c->d_stamps, 48));
+    CREATE_HIP(hipMemsetAsync(c->d_stamps, 0, sizeof(unsigned long long) * 48, c->stream));
 
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -1980,6 +1981,20 @@ int wfpt_debug_read_stamps(wfpt_ctx *c, uint64_t out[16], int reset) {
     WFPT_HIP(c, hipStreamSynchronize(c->stream));
     WFPT_HIP(c, hipMemcpy(out, c->d_stamps, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost));
     if (reset) WFPT_HIP(c, hipMemset(c->d_stamps, 0, sizeof(uint64_t) * 16));
+    return WFPT_OK;
+}
+
+int wfpt_debug_read_stamps_ex(wfpt_ctx *c, int which, uint64_t out[16], int reset) {
+    // which = 1 / 2: the refill traversal's first / middle launches (scenes beyond LDS), per wave summed: [0] loop iterations, [1] lanes holding a
+    // ray, [2] four-box visit steps, [3] lanes in them, [4] leaf rounds, [5] lanes in them, [6] refill passes, [7] lanes refilled, [8] lanes that sat
+    // at a leaf through an iteration without a leaf round; shader cycles: [9] refill, [10] visit step, [11] leaf round + result, [12] whole loop;
+    // [13] waves. which = 0: wfpt_debug_read_stamps.
+    if (which == 0) return wfpt_debug_read_stamps(c, out, reset);
+    if (!c || !out || which < 0 || which > 2) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_debug_read_stamps_ex: bad argument");
+    WFPT_HIP(c, hipSetDevice(c->device));
+    WFPT_HIP(c, hipStreamSynchronize(c->stream));
+    WFPT_HIP(c, hipMemcpy(out, c->d_stamps + 16 * which, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost));
+    if (reset) WFPT_HIP(c, hipMemset(c->d_stamps + 16 * which, 0, sizeof(uint64_t) * 16));
     return WFPT_OK;
 }
 

@@ -310,6 +310,7 @@ constexpr uint32_t kRefillIdle = WFPT_REFILL_IDLE, kRefillIdleFirst = WFPT_REFIL
 
 struct RefillArgs {
     Batch batch;
+    unsigned long long *stamps; // diagnostic builds (-DWFPT_STAMPS=1): 16 counters per launch kind, see wfpt_debug_read_stamps_ex
     const float4 *rec_in;  // compact hit records of the previous wavefront
     float4 *dense_out;     // [batch][capacity][2]: (p | pixel), (d | prim or kDenseMiss / kDenseInactive), indexed by ray
     const uint32_t *in_hits, *in_hit_base, *in_first_seg;

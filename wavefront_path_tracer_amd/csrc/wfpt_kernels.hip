@@ -663,6 +663,9 @@ __device__ __forceinline__ bool retrace_reference(const float4 *nodes, const flo
 __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((WFPT_AS_LDS const char *)p));
 }
+// ... of a pointer `p` derived from the kernel's `extern __shared__` array `base`: as a distance from that array, whose own address the
+// compiler knows (a cast of a generic pointer back to LDS costs a null check and an aperture compare wherever it is rematerialised)
+#define WFPT_LDS_BYTES(base, p) (lds_offset(base) + static_cast<uint32_t>(reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(base)))
 // The inner-node loop of trace_ray_conservative -- every lane that sits on an inner node (prim_count == 0) visits node pairs until it sits
 // on a leaf or its walk is over (prim_count = kWalkDone) -- written by hand, because what bounds the launch is instruction ISSUE, of both
 // kinds: hipcc's structurizer turns the loop nest (visit | pop with its parent-table walk) into 34-36 scalar mask instructions and
@@ -675,8 +678,18 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 //   pop: nothing pending -> done; else climb `ffbl(trail)` levels through the u16 parent table, take the sibling, read its fields.
 // exec is narrowed to the lanes still in the loop and restored at the end. The node pair lands in v[48:63], named in the clobber list (an
 // inline-asm operand cannot name the components of a 128-bit register tuple).
+#if WFPT_STAMPS // diagnostic builds count the wave's trips through the loop (a scalar) and every lane's own visits
+#define WFPT_ASM_COUNT "s_add_u32 %[dbgw], %[dbgw], 1\n\tv_add_u32_e32 %[dbgl], 1, %[dbgl]\n\t"
+#define WFPT_ASM_COUNT_OPS , [dbgw] "+s"(dbg_wave), [dbgl] "+v"(dbg_lane)
+#else
+#define WFPT_ASM_COUNT
+#define WFPT_ASM_COUNT_OPS
+#endif
 __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_lds, float bx, float by, float bz, float nox, float noy, float noz,
-                                            float nearest, uint32_t &node, uint32_t &left_first, uint32_t &prim_count, uint32_t &trail) {
+                                            float nearest, uint32_t &node, uint32_t &left_first, uint32_t &prim_count, uint32_t &trail WFPT_DBG_PARAM) {
+#if WFPT_STAMPS
+    uint32_t dbg_wave = __builtin_amdgcn_readfirstlane(dbg[0]), dbg_lane = dbg[2];
+#endif
     unsigned long long m_save, m_cur, m_l, m_r, m_go, m_t;
     float t1, t2; // every other temporary is a register of the node pair whose value has been consumed (the kernel has 64 vector registers)
     asm volatile(
@@ -684,7 +697,7 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
         "v_cmp_eq_u32_e32 vcc, 0, %[pc]\n\t"
         "s_and_b64 exec, exec, vcc\n\t"
         "s_cbranch_execz .Lwfpt_end%=\n"
-        ".Lwfpt_loop%=:\n\t"
+        ".Lwfpt_loop%=:\n\t" WFPT_ASM_COUNT
         "v_lshl_add_u32 %[t2], %[lf], 5, %[nodes]\n\t"
         "ds_read_b128 v[48:51], %[t2]\n\t"            // left:  centre.xyz | left_first
         "ds_read_b128 v[52:55], %[t2] offset:16\n\t"  //        half.xyz   | prim_count
@@ -771,10 +784,14 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
         ".Lwfpt_end%=:\n\t"
         "s_mov_b64 exec, %[save]"
         : [node] "+v"(node), [lf] "+v"(left_first), [pc] "+v"(prim_count), [trail] "+v"(trail), [save] "=&s"(m_save), [cur] "=&s"(m_cur),
-          [ml] "=&s"(m_l), [mr] "=&s"(m_r), [mgo] "=&s"(m_go), [mt] "=&s"(m_t), [t1] "=&v"(t1), [t2] "=&v"(t2)
+          [ml] "=&s"(m_l), [mr] "=&s"(m_r), [mgo] "=&s"(m_go), [mt] "=&s"(m_t), [t1] "=&v"(t1), [t2] "=&v"(t2) WFPT_ASM_COUNT_OPS
         : [nodes] "s"(nodes_lds), [parent] "s"(parent_lds), [bx] "v"(bx), [by] "v"(by), [bz] "v"(bz), [nox] "v"(nox), [noy] "v"(noy), [noz] "v"(noz),
           [nearest] "v"(nearest)
         : "vcc", "scc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+#if WFPT_STAMPS
+    dbg[0] = dbg_wave;
+    dbg[2] = dbg_lane;
+#endif
 }
 
 #ifndef WFPT_WALK_V1
@@ -872,9 +889,9 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
         }                                                                                                                              \
     } while (0)
     while (prim_count != kWalkDone) {
-        if (WFPT_WALK_ASM && !WFPT_STAMPS && sizeof(Trail) == 4 && sizeof(ParentT) == 2) { // inner nodes (ex:105-138), hand-written loop
+        if (WFPT_WALK_ASM && sizeof(Trail) == 4 && sizeof(ParentT) == 2) { // inner nodes (ex:105-138), hand-written loop
             uint32_t trail32 = static_cast<uint32_t>(trail);
-            descend_asm(nodes_lds, parent_lds, bx, by, bz, nox, noy, noz, nearest, node, left_first, prim_count, trail32);
+            descend_asm(nodes_lds, parent_lds, bx, by, bz, nox, noy, noz, nearest, node, left_first, prim_count, trail32 WFPT_DBG_ARG);
             trail = static_cast<Trail>(trail32);
         } else
         while (prim_count == 0u) { // inner nodes (ex:105-138)
@@ -939,34 +956,55 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
 // the stride are uniform and the index is 32-bit, so neither access needs a per-lane 64-bit pointer -- a version that kept
 // "this lane's column" as pointers had them spilled to scratch and re-loaded at every pop -- and the LDS and the global access
 // stay two instructions of their own address space (a select between the two pointers would make every access a flat one).
-// (the lane index is re-derived with two v_mbcnt at every use -- as volatile asm, or the compiler hoists it out of the loop and,
-// short of registers, parks it in scratch: a scratch re-load in front of every pop)
-__device__ __forceinline__ uint32_t lane_id_now() {
-    uint32_t l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
+// Round 5: the stack pointer IS the LDS byte address of the lane's next free entry (`top` = area + sp * kRow + 4 * thread): a push that
+// stays in LDS is one ds_write and one add, a pop one subtract and one ds_read, and "empty" / "in LDS" / "room for three more" are
+// compares of `top` with uniform bounds -- where rounds 3-4 kept the index sp and rebuilt the address (two v_mbcnt, two shifts, an add3)
+// behind an LDS / spill branch at every one of a visit's three push sites and two pop sites (~9 vector + 7 scalar instructions per site).
+// push_lds / pop_lds are for the caller that has checked, once per visit and for the whole wave, that no lane leaves the LDS column
+// (room3 / all_in_lds); push / pop keep the general form (spill to global memory beyond kStack4Lds entries).
 struct Stack4 {
-    uint32_t *lds;    // s_stack (uniform)
+    static constexpr uint32_t kRow = 4u * kExtendThreads; // bytes between two entries of a lane
+    uint32_t area;    // LDS byte offset of the stack area, [kStack4Lds][kExtendThreads] words (uniform)
     uint32_t *spill;  // the spill area (uniform)
     uint32_t stride;  // (uniform)
-    uint32_t wave0;   // first thread of this wave within the workgroup (uniform)
-    uint32_t sp = 0;
+    uint32_t top;     // this lane's next free entry, as an LDS byte address (entries beyond the column: the address they would have)
+    __device__ __forceinline__ void init(uint32_t lds_area_bytes, uint32_t *spill_area, uint32_t spill_stride) {
+        area = uniform(lds_area_bytes);
+        spill = spill_area;
+        stride = spill_stride;
+        top = area + 4u * threadIdx.x;
+    }
+    __device__ __forceinline__ void reset() { top = area + ((top - area) & (kRow - 1u)); }
+    __device__ __forceinline__ bool empty() const { return top < area + kRow; }
+    __device__ __forceinline__ bool room3() const { return top < area + (kStack4Lds - 2u) * kRow; } // three more pushes stay in LDS
+    __device__ __forceinline__ bool in_lds() const { return top < area + (kStack4Lds + 1u) * kRow; } // the top entry (if any) is in LDS
+    __device__ __forceinline__ void push_lds(uint32_t w) {
+        *(WFPT_AS_LDS uint32_t *)(uintptr_t)top = w;
+        top += kRow;
+    }
+    __device__ __forceinline__ uint32_t pop_lds() {
+        top -= kRow;
+        return *(const WFPT_AS_LDS uint32_t *)(uintptr_t)top;
+    }
+    __device__ __forceinline__ size_t spill_slot(uint32_t at) const { // of the entry whose LDS address would be `at`
+        const uint32_t sp = (at - area) / kRow, thread = ((at - area) & (kRow - 1u)) >> 2;
+        return static_cast<size_t>(sp - kStack4Lds) * stride + blockIdx.x * kExtendThreads + thread;
+    }
     __device__ __forceinline__ void push(uint32_t w) {
-        if (sp < kStack4Lds) {
-            ((WFPT_AS_LDS uint32_t *)lds)[sp * kExtendThreads + wave0 + lane_id_now()] = w;
+        if (top < area + kStack4Lds * kRow) {
+            *(WFPT_AS_LDS uint32_t *)(uintptr_t)top = w;
         } else {
-            ((WFPT_AS_GLOBAL uint32_t *)spill)[(sp - kStack4Lds) * stride + blockIdx.x * kExtendThreads + wave0 + lane_id_now()] = w;
+            ((WFPT_AS_GLOBAL uint32_t *)spill)[spill_slot(top)] = w;
         }
-        sp += 1;
+        top += kRow;
     }
     __device__ __forceinline__ uint32_t pop() {
-        sp -= 1;
+        top -= kRow;
         uint32_t w;
-        if (sp < kStack4Lds) {
-            w = ((const WFPT_AS_LDS uint32_t *)lds)[sp * kExtendThreads + wave0 + lane_id_now()];
+        if (top < area + kStack4Lds * kRow) {
+            w = *(const WFPT_AS_LDS uint32_t *)(uintptr_t)top;
         } else {
-            w = ((const WFPT_AS_GLOBAL uint32_t *)spill)[(sp - kStack4Lds) * stride + blockIdx.x * kExtendThreads + wave0 + lane_id_now()];
+            w = ((const WFPT_AS_GLOBAL uint32_t *)spill)[spill_slot(top)];
         }
         return w;
     }
@@ -1077,7 +1115,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
             if (budget-- == 0) { alive = false; break; }
             const Visit4 v = visit4_at(nodes4, nullptr, 0u, cur, r4, nearest);
             if (v.t0 >= 2e30f) { // nothing to enter
-                if (st.sp == 0) alive = false; else cur = st.pop();
+                if (st.empty()) alive = false; else cur = st.pop();
             } else {
                 if (v.t3 < 2e30f) st.push(v.w3); // farthest first, so the nearer ones pop first
                 if (v.t2 < 2e30f) st.push(v.w2);
@@ -1091,7 +1129,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
             // after the walk (leaf_box_verdict)
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
             visit_leaf<PRIM>(prim_geom, first, count, cur, ox, oy, oz, dx, dy, dz, a, nearest, best, best_leaf);
-            if (st.sp == 0) alive = false; else cur = st.pop();
+            if (st.empty()) alive = false; else cur = st.pop();
         }
     }
     leaf_box_verdict<PRIM>(prim_geom, best_leaf & kLeafFirstMask, (best_leaf >> kLeafCountShift) & 7u, root_leaf, ox, oy, oz, dx, dy, dz, nearest, best);
@@ -1195,9 +1233,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
                     hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_sphere, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
-                st.lds = s_stack;
-                st.stride = a.scene.spill_stride;
-                st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+                st.init(WFPT_LDS_BYTES(lds, s_stack), a.scene.stack_spill, a.scene.spill_stride);
                 prim = kHandOver;
                 if (!far_origin(a.scene, ox, oy, oz))
                     hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
@@ -1838,9 +1874,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                     hit = retrace_reference<Trail, PRIM, uint16_t>(g_nodes, s_geom, s_parent, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, t, prim);
             } else if (!EXACT && a.scene.nodes4) {
                 Stack4 st;
-                st.lds = L.stack;
-                st.stride = a.scene.spill_stride;
-                st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+                st.init(WFPT_LDS_BYTES(lds, L.stack), a.scene.stack_spill, a.scene.spill_stride);
                 prim = kHandOver;
                 if (!far_origin(a.scene, ox, oy, oz))
                     hit = trace_ray4<PRIM>(a.scene.nodes4, a.scene.prim_geom, st, ox, oy, oz, dx, dy, dz, a.scene.n_nodes, a.scene.root_leaf != 0, t, prim);
@@ -2386,9 +2420,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     const uint32_t lane = lane_id();
     uint32_t smp_cur = 0; // sample of the last group's first ray: a wave's tickets only grow, so the search goes on from there
     Stack4 st;
-    st.lds = s_stack;
-    st.stride = a.scene.spill_stride;
-    st.spill = a.scene.stack_spill; st.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    st.init(WFPT_LDS_BYTES(lds, s_stack), a.scene.stack_spill, a.scene.spill_stride);
     const float4 *nodes4 = a.scene.nodes4;
 
     // per-lane ray and traversal state
@@ -2403,7 +2435,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
     // cursor's atomic -- a round trip of microseconds that the whole wave waits for -- is paid once per kTicketBlock rays, not at
     // every refill (which made early refills, i.e. fuller waves, cost more than they brought).
     uint32_t cur_ray = 0, end_ray = 0;
+#if WFPT_STAMPS
+    // per wave, in registers: [0] iterations, [1] lanes holding a ray, [2] visit steps, [3] lanes visiting, [4] leaf rounds, [5] lanes in them,
+    // [6] refill passes, [7] lanes refilled, [8] lanes that waited at a leaf through an iteration; cycles: [0] refill, [1] visit step, [2] leaf round
+    unsigned long long st_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_c[3] = {0, 0, 0};
+    const unsigned long long st_t0 = stamp_now();
+#endif
     for (;;) {
+        WFPT_STAMP(st_a);
         // ---------------- refill: idle lanes take the next rays
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
@@ -2433,6 +2472,9 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 if (left == 0) first_g = b0;
             }
             while (first_g < total && first_g >= uniform(s_first[smp_cur + 1])) ++smp_cur; // scalar
+#if WFPT_STAMPS
+            st_n[6] += 1; st_n[7] += static_cast<unsigned long long>(__popcll(__ballot(!alive && take)));
+#endif
             if (!alive && take) {
                 smp = smp_cur;
                 while (g >= s_first[smp + 1]) ++smp; // a group rarely straddles samples
@@ -2471,7 +2513,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 }
                 if (ok) {
                     r4 = make_ray4(ox, oy, oz, dx, dy, dz);
-                    nearest = 1e30f; best = 0xffffffffu; cur = 0; st.sp = 0; budget = a.scene.n_nodes;
+                    nearest = 1e30f; best = 0xffffffffu; cur = 0; st.reset(); budget = a.scene.n_nodes;
                     alive = true;
                     if (far_origin(a.scene, ox, oy, oz)) hand_over(nearest, best); // (the walk then runs out at once; the re-trace at its end decides)
                 }
@@ -2488,17 +2530,33 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         // lanes waiting in the inner loop (691 Mrays/s on the 1M-triangle soup), while the leaf code (~80 instructions per
         // triangle) is cheap next to a four-box visit (~180): running it every iteration costs less than the waiting did (1024).
         bool fin = false;
+        WFPT_STAMP(st_b);
+#if WFPT_STAMPS
+        st_c[0] += st_b - st_a;
+        st_n[0] += 1; st_n[1] += static_cast<unsigned long long>(__popcll(__ballot(alive)));
+        { const unsigned long long vm = __ballot(alive && (cur & kLeafFlag) == 0); if (vm) { st_n[2] += 1; st_n[3] += static_cast<unsigned long long>(__popcll(vm)); } }
+#endif
         if (alive && (cur & kLeafFlag) == 0) {
             if (budget-- == 0) {
                 fin = true;
             } else {
             const Visit4 v = visit4_at(nodes4, s_tile, tile_n, cur, r4, nearest);
+            // (the whole wave takes the LDS-only form of the stack operations unless one of its lanes is within three entries of the
+            // column's end / holds spilled entries: 0.3 % of the pushes go deeper than kStack4Lds)
             if (v.t0 >= 2e30f) {
-                if (st.sp == 0) fin = true; else cur = st.pop();
+                if (st.empty()) fin = true;
+                else if (__ballot(!st.in_lds()) == 0) cur = st.pop_lds();
+                else cur = st.pop();
             } else {
-                if (v.t3 < 2e30f) st.push(v.w3);
-                if (v.t2 < 2e30f) st.push(v.w2);
-                if (v.t1 < 2e30f) st.push(v.w1);
+                if (__ballot(!st.room3()) == 0) {
+                    if (v.t3 < 2e30f) st.push_lds(v.w3);
+                    if (v.t2 < 2e30f) st.push_lds(v.w2);
+                    if (v.t1 < 2e30f) st.push_lds(v.w1);
+                } else {
+                    if (v.t3 < 2e30f) st.push(v.w3);
+                    if (v.t2 < 2e30f) st.push(v.w2);
+                    if (v.t1 < 2e30f) st.push(v.w1);
+                }
                 cur = v.w0;
             }
             }
@@ -2507,6 +2565,11 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         // lanes wait at a leaf to be worth the wave's time, or when no lane has a node to visit.
         const bool at_leaf = alive && !fin && (cur & kLeafFlag) != 0;
         const bool leaf_round = __popcll(__ballot(at_leaf)) >= WFPT_LEAF_LANES || __ballot(alive && !fin && !at_leaf) == 0;
+        WFPT_STAMP(st_c0);
+#if WFPT_STAMPS
+        st_c[1] += st_c0 - st_b;
+        { const unsigned long long lm = __ballot(at_leaf); if (lm && leaf_round) { st_n[4] += 1; st_n[5] += static_cast<unsigned long long>(__popcll(lm)); } else st_n[8] += static_cast<unsigned long long>(__popcll(lm)); }
+#endif
         if (at_leaf && leaf_round) { // at a leaf child
             if (budget-- == 0) {
                 fin = true;
@@ -2514,9 +2577,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
                 const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 7u;
                 const float aa = (dx * dx + dy * dy) + dz * dz;              // dot(direction, direction), ex:190
                 visit_leaf_in_place<PRIM, true>(a.scene.prim_geom, first, count, a.scene.root_leaf != 0, r4.ox, r4.oy, r4.oz, dx, dy, dz, 0.f, 0.f, 0.f, aa, nearest, best); // see trace_ray4
-                if (st.sp == 0) fin = true; else cur = st.pop();
+                if (st.empty()) fin = true;
+                else if (__ballot(!st.in_lds()) == 0) cur = st.pop_lds();
+                else cur = st.pop();
             }
         }
+#if WFPT_STAMPS
+        { const unsigned long long st_d = stamp_now(); st_c[2] += st_d - st_c0; }
+#endif
         if (alive && fin) { // the ray is done: dense record in ray order (p = o + t d as shade reads it, sh:91)
             if (best == kHandOver) // rare: the reference's own walk over the caller's binary tree decides
                 (void)retrace_reference<unsigned long long, PRIM, uint32_t>(reinterpret_cast<const float4 *>(a.scene.nodes), a.scene.prim_geom,
@@ -2529,6 +2597,15 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
             alive = false;
         }
     }
+#if WFPT_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long *out = a.stamps + (MODE == kBounceFirst ? 16 : 32);
+        for (int k = 0; k < 9; ++k) atomicAdd(&out[k], st_n[k]);
+        for (int k = 0; k < 3; ++k) atomicAdd(&out[9 + k], st_c[k]);
+        atomicAdd(&out[12], stamp_now() - st_t0);
+        atomicAdd(&out[13], 1ull);
+    }
+#endif
 }
 
 // shade (sh:56-156) of every hit of the previous wavefront at full waves, for the refill traversal: one workgroup = one run of
