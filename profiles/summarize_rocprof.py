@@ -84,7 +84,7 @@ def main():
     line = json.load(open(base + "stats.json"))
     json.dump(line, open(os.path.join(here, f"{rnd}_bench_line_{scene}_{variant}.json"), "w"), indent=1)
     out = {}
-    for d in ("fetch", "write", "sq", "sq2", "sq3", "sq4", "sq5", "sqc", "tcc", "tcp", "ta", "ta2"):
+    for d in ("fetch", "write", "sq", "sq2", "sq3", "sq4", "sq5", "sq6", "sqc", "tcc", "tcp", "ta", "ta2"):
         for p in newest(base + d + "/*/*_counter_collection.csv"):
             for k, counters in pmc(p).items():
                 for c, v in counters.items():

@@ -63,6 +63,8 @@ struct wfpt_ctx {
     RayQueue q[2]{};
     int cur = 0; // which queue is "ray_buffer"; the other one is "extension_ray_buffer"
     uint32_t *hit_mem = nullptr, *miss_mem = nullptr; // 3 planes each: (t, prim, ray index) / (ray index, dir.y, pixel)
+    float4 *hit_rec = nullptr; // [classic_batch][capacity][2]: the path record extend leaves beside the hit queue for shade to stream
+    bool hit_rec_valid = false; // slice 0's records describe the hit queue AND the ray queue as they are (stage API: a host may touch either between stages)
     HitQueue hq{};
     MissQueue mq{};
     float4 *d_shade_rec = nullptr;
@@ -248,6 +250,7 @@ ExtendArgs extend_args(wfpt_ctx *c, int qi, const uint32_t *n_in, uint32_t limit
     a.mq = c->mq;
     a.chunk_hits = c->chunk_hits;
     a.chunk_miss = c->chunk_miss;
+    a.rec_out = c->hit_rec;
     a.ctl = c->ctl;
     a.n_in = n_in;
     a.limit = std::min(limit, c->capacity);
@@ -288,6 +291,7 @@ ShadeArgs shade_args(wfpt_ctx *c, int qi, const uint32_t *n_hits, uint32_t limit
     a.ext = c->q[qi ^ 1];
     a.hq = c->hq;
     a.chunk_hits = c->chunk_hits; a.chunk_hit_base = c->chunk_hit_base;
+    a.rec_in = c->hit_rec_valid ? c->hit_rec : nullptr;
     a.image = c->image;
     a.ctl = c->ctl;
     a.n_hits = n_hits;
@@ -552,13 +556,15 @@ int enqueue_batch(wfpt_ctx *c, std::vector<EventRec> *ev, uint32_t nb) {
                           [&] { return launch_scan(scan_args(c, &c->ctl->n_in, c->capacity, true, b, nb), c->stream); }));
         if (split) { // one launch, blockIdx.z = material class (README.md:19's by-material shade kernels)
             WFPT_HIP(c, timed(WFPT_STAGE_SHADE_LAMBERTIAN, [&] {
-                         return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb),
-                                             consumer_grid(c, nb), c->stream);
+                         ShadeArgs sa = shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb);
+                         sa.rec_in = c->hit_rec; // this wavefront's extend has just written them
+                         return launch_shade(sa, consumer_grid(c, nb), c->stream);
                      }));
         } else {
             WFPT_HIP(c, timed(WFPT_STAGE_SHADE, [&] {
-                         return launch_shade(shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb),
-                                             consumer_grid(c, nb), c->stream);
+                         ShadeArgs sa = shade_args(c, qi, &c->ctl->shade_n, c->capacity, 0, 0xffffffffu, false, nb);
+                         sa.rec_in = c->hit_rec; // this wavefront's extend has just written them
+                         return launch_shade(sa, consumer_grid(c, nb), c->stream);
                      }));
         }
         WFPT_HIP(c, timed(WFPT_STAGE_MISS, [&] {
@@ -606,6 +612,7 @@ int render_batch(wfpt_ctx *c, uint32_t nb) {
         WFPT_HIP(c, hipGraphLaunch(it->second.second, c->stream));
     }
     c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
+    c->hit_rec_valid = false;     // (the stage API starts from the queues as the loop left them)
     c->progress_frame += nb;      // the device advanced ctl->frame.frame itself
     c->accumulated_samples += nb; // pt:363
     c->last_slot = nb - 1;
@@ -1132,6 +1139,7 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
         set_queue(c->q[k], c->ray_mem[k], c->capacity);
     }
     CREATE_HIP(dmalloc(&c->hit_mem, 3 * nb * c->capacity));
+    CREATE_HIP(dmalloc(&c->hit_rec, 2 * nb * c->capacity));
     CREATE_HIP(dmalloc(&c->miss_mem, 3 * nb * c->capacity));
     if (nb * c->capacity > 0xffffffffull || nb_all * c->capacity > 0xffffffffull) {
         fail(nullptr, WFPT_ERR_UNSUPPORTED, "wfpt_create: samples in flight x ray capacity beyond 2^32 queue slots");
@@ -1312,7 +1320,7 @@ void wfpt_destroy(wfpt_ctx *c) {
     free_scene(c);
     void *bufs[] = {c->rec_dense, c->rec_mem[0], c->rec_mem[1], c->f_miss_mem[0], c->f_miss_mem[1], c->f_chunk_hits[0], c->f_chunk_hits[1],
                     c->f_chunk_miss[0], c->f_chunk_miss[1], c->first_seg, c->f_cls[0], c->f_cls[1], c->first_seg_cls, c->plan, c->cls_table,
-                    c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->miss_mem, c->chunk_hits,
+                    c->ray_mem[0], c->ray_mem[1], c->hit_mem, c->hit_rec, c->miss_mem, c->chunk_hits,
                     c->chunk_miss, c->chunk_hit_base, c->chunk_miss_base, c->mat_list, c->chunk_mat, c->image, c->accumulated, c->ctl,
                     c->camera, c->d_stamps};
     for (void *b : bufs)
@@ -1335,6 +1343,7 @@ int wfpt_update_render_parameters(wfpt_ctx *c, uint32_t width, uint32_t height, 
     if (!c || !camera || !inv_proj || !view || width == 0 || height == 0)
         return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_render_parameters: null or empty argument");
     WFPT_HIP(c, hipSetDevice(c->device));
+    c->hit_rec_valid = false;
     wfpt_ctx probe;
     probe.tile = c->tile;
     set_viewport(&probe, width, height);
@@ -1373,6 +1382,7 @@ static int update_scene_impl(wfpt_ctx *c, wfpt_sphere *spheres, wfpt_triangle *t
             return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_update_scene: primitive material_idx out of range");
     WFPT_HIP(c, hipSetDevice(c->device));
     WFPT_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still read the old scene
+    c->hit_rec_valid = false;
     std::vector<wfpt_bvh_node> nodes(2 * static_cast<size_t>(n_prims));
     uint32_t n_nodes = 0;
     const int st = spheres ? wfpt_build_bvh_device(spheres, n_prims, nodes.data(), static_cast<uint32_t>(nodes.size()), &n_nodes, c->device, nullptr)
@@ -1443,6 +1453,7 @@ int wfpt_reset_progress(wfpt_ctx *c) {
 
 int wfpt_clear_ray_queues(wfpt_ctx *c) {
     if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    c->hit_rec_valid = false;
     WFPT_HIP(c, hipSetDevice(c->device));
     for (int k = 0; k < 2; ++k)
         WFPT_HIP(c, hipMemsetAsync(c->ray_mem[k], 0, sizeof(float) * 7 * static_cast<size_t>(c->capacity), c->stream));
@@ -1451,6 +1462,7 @@ int wfpt_clear_ray_queues(wfpt_ctx *c) {
 
 int wfpt_swap_ray_queues(wfpt_ctx *c) {
     if (!c) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "null context");
+    c->hit_rec_valid = false; // shade.wgsl:76-78 reads ray_buffer[hit.ray_idx] as it is when shade runs: after a swap, not extend's rays
     c->cur ^= 1;
     return WFPT_OK;
 }
@@ -1476,11 +1488,13 @@ int wfpt_kernel_run(wfpt_ctx *c, int stage, uint32_t gx, uint32_t gy) {
     if (int r = stage_begin(c, stage); r != WFPT_OK) return r;
     switch (stage) {
     case WFPT_STAGE_GENERATE_RAYS:
+        c->hit_rec_valid = false;
         WFPT_HIP(c, launch_generate(generate_args(c, gx, gy, false), c->stream));
         break;
     case WFPT_STAGE_EXTEND:
         WFPT_HIP(c, launch_extend(extend_args(c, c->cur, &c->ctl->counters[2], threads), extend_grid(c, 1), c->stream));
         WFPT_HIP(c, launch_scan(scan_args(c, &c->ctl->counters[2], threads, false, 0), c->stream));
+        c->hit_rec_valid = true; // shade may stream extend's path records until the host touches the ray queue (generate_rays, write, swap, clear)
         break;
     case WFPT_STAGE_SHADE:
         WFPT_HIP(c, launch_shade(shade_args(c, c->cur, &c->ctl->counters[1], threads, gx, 0xffffffffu, true),
@@ -1550,6 +1564,7 @@ int wfpt_render_timed(wfpt_ctx *c, uint32_t n_samples, float *stage_ms, uint32_t
             if (stage_launches) stage_launches[e.stage] += 1;
         }
         c->cur = static_cast<int>(c->p.max_wavefronts & 1u);
+        c->hit_rec_valid = false;
         c->progress_frame += nb;
         c->accumulated_samples += nb;
         c->last_slot = nb - 1;
@@ -1637,6 +1652,7 @@ int wfpt_read_extension_rays(wfpt_ctx *c, wfpt_ray *rays, uint32_t n) {
 int wfpt_write_rays(wfpt_ctx *c, const wfpt_ray *rays, uint32_t n) {
     if (!c || !rays) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: null argument");
     if (n > c->capacity) return fail(c, WFPT_ERR_INVALID_ARGUMENT, "wfpt_write_rays: n exceeds the queue capacity");
+    c->hit_rec_valid = false;
     if (n == 0) return WFPT_OK;
     // shade and miss_kernel index the image with the ray's pixel_idx: it must name a pixel this context holds
     for (uint32_t i = 0; i < n; ++i) {

@@ -183,6 +183,10 @@ struct ExtendArgs {
     HitQueue hq;
     MissQueue mq;         // payload: direction.y and pixel of the missing ray, so miss_kernel needs no gather
     uint32_t *chunk_hits, *chunk_miss;
+    // Beside the reference's hit queue (t, primitive, ray index: what wfpt_read_hits returns) extend leaves the path record the fused loop
+    // carries -- (hit point | pixel), (incoming direction | primitive), two float4 at the hit's slot -- so that shade STREAMS 32 bytes per hit
+    // instead of gathering seven planes of the ray queue through the ray index (round 5; null = not written)
+    float4 *rec_out;
     Control *ctl;
     const uint32_t *n_in; // rays to trace = min(*n_in, limit)
     uint32_t limit;
@@ -337,6 +341,7 @@ struct ShadeArgs {
     RayQueue q, ext;
     HitQueue hq;
     const uint32_t *chunk_hits, *chunk_hit_base;
+    const float4 *rec_in;   // extend's path records of these hits (ExtendArgs::rec_out); null = gather the ray through hq.ridx() as shade.wgsl:76-78 does
     float *image;
     Control *ctl;
     const uint32_t *n_hits; // hits to shade = min(*n_hits, limit)

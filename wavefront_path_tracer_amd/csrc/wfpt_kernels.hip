@@ -1281,6 +1281,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
             a.hq.t()[slot] = t;
             a.hq.prim()[slot] = prim;
             a.hq.ridx()[slot] = idx;
+            if (a.rec_out) { // what shade will need of this hit, in one place: p = origin + t * direction (sh:91), the direction, pixel, primitive
+                a.rec_out[2u * slot] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(q.pixel()[idx]));
+                a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
+            }
         }
         if (miss) { // ex:61, plus what miss_kernel reads of the ray (mk:29-32)
             const size_t slot = seg + miss_before + mbcnt(miss_mask);
@@ -1538,6 +1542,43 @@ __global__ __launch_bounds__(kConsumerThreads) void shade_kernel(ShadeArgs a) {
         const uint32_t count = split ? chunk_mat[chunk] : a.chunk_hits[chunk];
         const uint32_t base = a.chunk_hit_base[chunk];
         if (base >= n_hits) break; // bases ascend with the segment index
+        if (a.rec_in) {
+            // ---- streaming form: extend left (hit point | pixel), (direction | primitive) at the hit's slot; the next hit's record is
+            // loaded before this hit's dependent gathers (shade record, throughput)
+            const float4 *rec = a.rec_in + 2u * (sample * static_cast<size_t>(a.batch.queue_stride) + static_cast<size_t>(chunk) * kChunk);
+            uint32_t r0 = threadIdx.x, nr = 0;
+            float4 nra = make_float4(0, 0, 0, 0), nrb = nra;
+            if (r0 < count) {
+                nr = split ? mat_list[chunk * kChunk + r0] : r0;
+                nra = rec[2u * nr]; nrb = rec[2u * nr + 1u];
+            }
+            for (; r0 < count; r0 += kConsumerThreads) {
+                const uint32_t r = nr;
+                const float4 ra = nra, rb = nrb;
+                const uint32_t h = base + r; // the reference's shade thread index
+                if (h >= n_hits) break;
+                if (r0 + kConsumerThreads < count) {
+                    nr = split ? mat_list[chunk * kChunk + r0 + kConsumerThreads] : r0 + kConsumerThreads;
+                    nra = rec[2u * nr]; nrb = rec[2u * nr + 1u];
+                }
+                if (split && a.count_out) { // per-material stage of the stage API: counters[2] += rays this stage emits
+                    const unsigned long long m = __ballot(true);
+                    if (lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1))
+                        atomicAdd(&a.ctl->counters[2], static_cast<uint32_t>(__popcll(m)));
+                }
+                const uint32_t prim = __float_as_uint(rb.w), pixel_idx = __float_as_uint(ra.w);
+                const float4 rec0 = a.scene.shade_rec[3u * prim], rec1 = a.scene.shade_rec[3u * prim + 1u], rec2 = a.scene.shade_rec[3u * prim + 2u];
+                float4 *px = pixel_of(a.image, local_pixel(pixel_idx, a.image_width, a.tile));
+                const float4 thr = *px; // sh:84-87: throughput *= albedo, for every material type (load now, store after the scatter math)
+                const uint32_t rng = shade_rng(a.rng_mode, h, gx, pixel_idx, fb);
+                const float3_ ext = scatter(rng, {ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, rec0, rec1, __float_as_uint(rec2.x), a.scene.prim_kind);
+                a.ext.ox()[h] = ra.x; a.ext.oy()[h] = ra.y; a.ext.oz()[h] = ra.z; // sh:153-155
+                a.ext.dx()[h] = ext.x; a.ext.dy()[h] = ext.y; a.ext.dz()[h] = ext.z;
+                a.ext.pixel()[h] = pixel_idx;
+                *px = make_float4(thr.x * rec1.x, thr.y * rec1.y, thr.z * rec1.z, thr.w); // albedo
+            }
+            continue;
+        }
         // Software-pipelined walk: the queue entry of the NEXT iteration is loaded before this iteration's
         // dependent gathers, so each hit costs two dependent memory levels instead of three.
         uint32_t r0 = threadIdx.x;
@@ -1717,8 +1758,11 @@ struct BounceLds {
 constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + 2u + kMaxBatch; // the two u16 tables take kMaxBatch words
 static_assert(kBounceMiscWords % 4u == 0, "the stack column area stays 16-byte aligned");
 
+#ifndef WFPT_BOUNCE_ATTR
+#define WFPT_BOUNCE_ATTR __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES)
+#endif
 template <int MODE, typename Trail, int PRIM, bool LDS_SCENE, bool EXACT>
-__global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_kernel(BounceArgs a) {
+__global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
     extern __shared__ float4 lds[];
     constexpr bool TRACE = MODE != kBounceLast;
     constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u;
