@@ -629,8 +629,9 @@ def main():
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": round(fabric, 1) if fabric else None,
-                           "traffic_source": (f"from_profile: {pmc['source']} ({pmc.get('samples_in_flight')} samples in flight, rocprofv3 --pmc of this command, "
-                                              f"commit {pmc.get('git_head')})" if fabric else None),
+                           "traffic_source": (f"from_profile: {pmc['source']} (rocprofv3 --pmc of this workload -- same scene and size, frame, samples per pixel and "
+                                              f"in flight, bounces, RNG mode and loop; the profile's own command: `{pmc.get('bench_command')}`, commit {pmc.get('git_head')})"
+                                              if fabric else None),
                            "traffic_note": ("FETCH_SIZE x the factor calibrated for this kernel's access shape + WRITE_SIZE: requests on the fabric side of L2 "
                                             "(MI355X_MICROARCH.md: Infinity-Cache hits are counted, so this is fabric traffic, an upper bound on HBM traffic); "
                                             + (pk.get("calibration_note") or "")) if fabric else None,

@@ -1758,6 +1758,9 @@ struct BounceLds {
 constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + 2u + kMaxBatch; // the two u16 tables take kMaxBatch words
 static_assert(kBounceMiscWords % 4u == 0, "the stack column area stays 16-byte aligned");
 
+#ifndef WFPT_EXP_NO_ITEM_BARRIER
+#define WFPT_EXP_NO_ITEM_BARRIER 0 // 1: measurement build, WRONG results: no workgroup barrier and no ticket inside a work item (what would wave-level items be worth?)
+#endif
 #ifndef WFPT_BOUNCE_ATTR
 #define WFPT_BOUNCE_ATTR __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES)
 #endif
@@ -1765,6 +1768,8 @@ template <int MODE, typename Trail, int PRIM, bool LDS_SCENE, bool EXACT>
 __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
     extern __shared__ float4 lds[];
     constexpr bool TRACE = MODE != kBounceLast;
+    constexpr bool kNoBar = WFPT_EXP_NO_ITEM_BARRIER && MODE == kBounceMiddle; // measurement builds only
+    if (WFPT_EXP_NO_ITEM_BARRIER && MODE == kBounceLast) return;               // (their middle launches leave no usable queue)
     constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u;
     const bool stage_scene = TRACE && LDS_SCENE;
     float4 *s_nodes = lds;
@@ -1827,7 +1832,7 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
 #endif
     while (item < n_items) {
         const uint32_t buf = iter & 1u;
-        if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        if (!kNoBar && threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         if (item >= n_hit_items) {
             // ---------------- miss_kernel (mk:13-38) for kMissSegsPerItem segments of the previous wavefront's miss queue
             while (item >= first_m + uniform(L.items_m[smp_m])) first_m += uniform(L.items_m[smp_m++]);
@@ -1855,8 +1860,12 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
                     *px = make_float4(thr.x * cr, thr.y * cg, thr.z * cb, thr.w); // mk:35-37
                 }
             }
-            __syncthreads(); // L.next[buf] is visible
-            item = uniform(L.next[buf]);
+            if (kNoBar) {
+                item += gridDim.x;
+            } else {
+                __syncthreads(); // L.next[buf] is visible
+                item = uniform(L.next[buf]);
+            }
             iter += 1;
             continue;
         }
@@ -1936,16 +1945,20 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
             L.cnt[(buf * 2 + 0) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(hit_mask));
             L.cnt[(buf * 2 + 1) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(miss_mask));
         }
-        __syncthreads();
+        if (!kNoBar) __syncthreads();
         WFPT_STAMP(t_synced);
         uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
+        if (kNoBar) { // measurement only (results are wrong): every wave compacts into its own 64 slots, nobody waits for anybody
+            hit_before = miss_before = wave * 64u;
+        } else {
 #pragma unroll
-        for (uint32_t w = 0; w < kExtendWaves; ++w) {
-            const uint32_t hc = uniform(L.cnt[(buf * 2 + 0) * kExtendWaves + w]), mc = uniform(L.cnt[(buf * 2 + 1) * kExtendWaves + w]);
-            hit_before += (w < wave) ? hc : 0u;
-            miss_before += (w < wave) ? mc : 0u;
-            hit_total += hc;
-            miss_total += mc;
+            for (uint32_t w = 0; w < kExtendWaves; ++w) {
+                const uint32_t hc = uniform(L.cnt[(buf * 2 + 0) * kExtendWaves + w]), mc = uniform(L.cnt[(buf * 2 + 1) * kExtendWaves + w]);
+                hit_before += (w < wave) ? hc : 0u;
+                miss_before += (w < wave) ? mc : 0u;
+                hit_total += hc;
+                miss_total += mc;
+            }
         }
         const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
         if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel
@@ -1981,7 +1994,7 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
             acc_cnt[2] += w_visits; acc_cnt[3] += w_leaves; acc_cnt[4] += l_visits;
         }
 #endif
-        item = uniform(L.next[buf]);
+        item = kNoBar ? item + gridDim.x : uniform(L.next[buf]);
         iter += 1;
     }
 #if WFPT_STAMPS
