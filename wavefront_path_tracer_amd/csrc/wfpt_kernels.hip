@@ -676,8 +676,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 //            entered <=> max(t_in, 0) <= t_out
 //   go_right = hit_r & (!hit_l | l_in > r_in); both -> the far child stays pending (trail bit); none -> pop
 //   pop: nothing pending -> done; else climb `ffbl(trail)` levels through the u16 parent table, take the sibling, read its fields.
-// exec is narrowed to the lanes still in the loop and restored at the end. The node pair lands in v[48:63], named in the clobber list (an
-// inline-asm operand cannot name the components of a 128-bit register tuple).
+// exec is narrowed to the lanes still in the loop and restored at the end. The node pair lands in v[32:47], named in the clobber list (an
+// inline-asm operand cannot name the components of a 128-bit register tuple; of the ranges tried, [48:63] left 8-14 dwords of scratch spill in
+// the bounce kernels, [32:47] and [16:31] none in the middle launches).
 #if WFPT_STAMPS // diagnostic builds count the wave's trips through the loop (a scalar) and every lane's own visits
 #define WFPT_ASM_COUNT "s_add_u32 %[dbgw], %[dbgw], 1\n\tv_add_u32_e32 %[dbgl], 1, %[dbgl]\n\t"
 #define WFPT_ASM_COUNT_OPS , [dbgw] "+s"(dbg_wave), [dbgl] "+v"(dbg_lane)
@@ -699,41 +700,41 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
         "s_cbranch_execz .Lwfpt_end%=\n"
         ".Lwfpt_loop%=:\n\t" WFPT_ASM_COUNT
         "v_lshl_add_u32 %[t2], %[lf], 5, %[nodes]\n\t"
-        "ds_read_b128 v[48:51], %[t2]\n\t"            // left:  centre.xyz | left_first
-        "ds_read_b128 v[52:55], %[t2] offset:16\n\t"  //        half.xyz   | prim_count
-        "ds_read_b128 v[56:59], %[t2] offset:32\n\t"  // right: centre.xyz | left_first
-        "ds_read_b128 v[60:63], %[t2] offset:48\n\t"  //        half.xyz   | prim_count
+        "ds_read_b128 v[32:35], %[t2]\n\t"            // left:  centre.xyz | left_first
+        "ds_read_b128 v[36:39], %[t2] offset:16\n\t"  //        half.xyz   | prim_count
+        "ds_read_b128 v[40:43], %[t2] offset:32\n\t"  // right: centre.xyz | left_first
+        "ds_read_b128 v[44:47], %[t2] offset:48\n\t"  //        half.xyz   | prim_count
         "s_mov_b64 %[cur], exec\n\t"
         "s_waitcnt lgkmcnt(2)\n\t"
-        "v_fma_f32 v48, v48, %[bx], %[nox]\n\t"       // tc = c * b - o * b
-        "v_fma_f32 v49, v49, %[by], %[noy]\n\t"
-        "v_fma_f32 v50, v50, %[bz], %[noz]\n\t"
-        "v_fma_f32 %[t1], v52, -|%[bx]|, v48\n\t"     // entry distances tc - h |b| ...
-        "v_fma_f32 v48, v52, |%[bx]|, v48\n\t"        // ... exit distances tc + h |b|
-        "v_fma_f32 v52, v53, -|%[by]|, v49\n\t"
-        "v_fma_f32 v49, v53, |%[by]|, v49\n\t"
-        "v_fma_f32 v53, v54, -|%[bz]|, v50\n\t"
-        "v_fma_f32 v50, v54, |%[bz]|, v50\n\t"
-        "v_max3_f32 %[t1], %[t1], v52, v53\n\t"       // l_in
-        "v_min_f32_e32 v48, v48, v49\n\t"
-        "v_min3_f32 v48, v48, v50, %[nearest]\n\t"
-        "v_max_f32_e32 v49, 0, %[t1]\n\t"
-        "v_cmp_le_f32_e64 %[ml], v49, v48\n\t"        // hit_l
+        "v_fma_f32 v32, v32, %[bx], %[nox]\n\t"       // tc = c * b - o * b
+        "v_fma_f32 v33, v33, %[by], %[noy]\n\t"
+        "v_fma_f32 v34, v34, %[bz], %[noz]\n\t"
+        "v_fma_f32 %[t1], v36, -|%[bx]|, v32\n\t"     // entry distances tc - h |b| ...
+        "v_fma_f32 v32, v36, |%[bx]|, v32\n\t"        // ... exit distances tc + h |b|
+        "v_fma_f32 v36, v37, -|%[by]|, v33\n\t"
+        "v_fma_f32 v33, v37, |%[by]|, v33\n\t"
+        "v_fma_f32 v37, v38, -|%[bz]|, v34\n\t"
+        "v_fma_f32 v34, v38, |%[bz]|, v34\n\t"
+        "v_max3_f32 %[t1], %[t1], v36, v37\n\t"       // l_in
+        "v_min_f32_e32 v32, v32, v33\n\t"
+        "v_min3_f32 v32, v32, v34, %[nearest]\n\t"
+        "v_max_f32_e32 v33, 0, %[t1]\n\t"
+        "v_cmp_le_f32_e64 %[ml], v33, v32\n\t"        // hit_l
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_fma_f32 v56, v56, %[bx], %[nox]\n\t"
-        "v_fma_f32 v57, v57, %[by], %[noy]\n\t"
-        "v_fma_f32 v58, v58, %[bz], %[noz]\n\t"
-        "v_fma_f32 %[t2], v60, -|%[bx]|, v56\n\t"
-        "v_fma_f32 v56, v60, |%[bx]|, v56\n\t"
-        "v_fma_f32 v60, v61, -|%[by]|, v57\n\t"
-        "v_fma_f32 v57, v61, |%[by]|, v57\n\t"
-        "v_fma_f32 v61, v62, -|%[bz]|, v58\n\t"
-        "v_fma_f32 v58, v62, |%[bz]|, v58\n\t"
-        "v_max3_f32 %[t2], %[t2], v60, v61\n\t"       // r_in
-        "v_min_f32_e32 v56, v56, v57\n\t"
-        "v_min3_f32 v56, v56, v58, %[nearest]\n\t"
-        "v_max_f32_e32 v57, 0, %[t2]\n\t"
-        "v_cmp_le_f32_e64 %[mr], v57, v56\n\t"        // hit_r
+        "v_fma_f32 v40, v40, %[bx], %[nox]\n\t"
+        "v_fma_f32 v41, v41, %[by], %[noy]\n\t"
+        "v_fma_f32 v42, v42, %[bz], %[noz]\n\t"
+        "v_fma_f32 %[t2], v44, -|%[bx]|, v40\n\t"
+        "v_fma_f32 v40, v44, |%[bx]|, v40\n\t"
+        "v_fma_f32 v44, v45, -|%[by]|, v41\n\t"
+        "v_fma_f32 v41, v45, |%[by]|, v41\n\t"
+        "v_fma_f32 v45, v46, -|%[bz]|, v42\n\t"
+        "v_fma_f32 v42, v46, |%[bz]|, v42\n\t"
+        "v_max3_f32 %[t2], %[t2], v44, v45\n\t"       // r_in
+        "v_min_f32_e32 v40, v40, v41\n\t"
+        "v_min3_f32 v40, v40, v42, %[nearest]\n\t"
+        "v_max_f32_e32 v41, 0, %[t2]\n\t"
+        "v_cmp_le_f32_e64 %[mr], v41, v40\n\t"        // hit_r
         "v_cmp_gt_f32_e32 vcc, %[t1], %[t2]\n\t"      // r_nearer = l_in > r_in
         "s_orn2_b64 %[mt], vcc, %[ml]\n\t"
         "s_and_b64 %[mgo], %[mt], %[mr]\n\t"          // go_right = hit_r & (r_nearer | !hit_l)
@@ -744,8 +745,8 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
         "v_addc_co_u32_e64 %[node], %[mr], 0, %[lf], %[mgo]\n\t" // node = left_first + go_right (the carry out is not used)
         "v_cndmask_b32_e64 %[t2], 0, 1, %[ml]\n\t"
         "v_lshl_or_b32 %[trail], %[trail], 1, %[t2]\n\t"
-        "v_cndmask_b32_e64 %[lf], v51, v59, %[mgo]\n\t"
-        "v_cndmask_b32_e64 %[pc], v55, v63, %[mgo]\n\t"
+        "v_cndmask_b32_e64 %[lf], v35, v43, %[mgo]\n\t"
+        "v_cndmask_b32_e64 %[pc], v39, v47, %[mgo]\n\t"
         // ---- pop (lanes that entered neither)
         "s_andn2_b64 exec, %[cur], %[mt]\n\t"
         "s_cbranch_execz .Lwfpt_next%=\n\t"
@@ -787,7 +788,7 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
           [ml] "=&s"(m_l), [mr] "=&s"(m_r), [mgo] "=&s"(m_go), [mt] "=&s"(m_t), [t1] "=&v"(t1), [t2] "=&v"(t2) WFPT_ASM_COUNT_OPS
         : [nodes] "s"(nodes_lds), [parent] "s"(parent_lds), [bx] "v"(bx), [by] "v"(by), [bz] "v"(bz), [nox] "v"(nox), [noy] "v"(noy), [noz] "v"(noz),
           [nearest] "v"(nearest)
-        : "vcc", "scc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+        : "vcc", "scc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
 #if WFPT_STAMPS
     dbg[0] = dbg_wave;
     dbg[2] = dbg_lane;
@@ -1758,9 +1759,6 @@ struct BounceLds {
 constexpr uint32_t kBounceMiscWords = 4u * kExtendWaves + 2u + 2u + kMaxBatch; // the two u16 tables take kMaxBatch words
 static_assert(kBounceMiscWords % 4u == 0, "the stack column area stays 16-byte aligned");
 
-#ifndef WFPT_EXP_NO_ITEM_BARRIER
-#define WFPT_EXP_NO_ITEM_BARRIER 0 // 1: measurement build, WRONG results: no workgroup barrier and no ticket inside a work item (what would wave-level items be worth?)
-#endif
 #ifndef WFPT_BOUNCE_ATTR
 #define WFPT_BOUNCE_ATTR __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES)
 #endif
@@ -1768,8 +1766,6 @@ template <int MODE, typename Trail, int PRIM, bool LDS_SCENE, bool EXACT>
 __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
     extern __shared__ float4 lds[];
     constexpr bool TRACE = MODE != kBounceLast;
-    constexpr bool kNoBar = WFPT_EXP_NO_ITEM_BARRIER && MODE == kBounceMiddle; // measurement builds only
-    if (WFPT_EXP_NO_ITEM_BARRIER && MODE == kBounceLast) return;               // (their middle launches leave no usable queue)
     constexpr uint32_t kGeomWords = PRIM == 0 ? 1u : 3u;
     const bool stage_scene = TRACE && LDS_SCENE;
     float4 *s_nodes = lds;
@@ -1832,7 +1828,7 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
 #endif
     while (item < n_items) {
         const uint32_t buf = iter & 1u;
-        if (!kNoBar && threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
+        if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         if (item >= n_hit_items) {
             // ---------------- miss_kernel (mk:13-38) for kMissSegsPerItem segments of the previous wavefront's miss queue
             while (item >= first_m + uniform(L.items_m[smp_m])) first_m += uniform(L.items_m[smp_m++]);
@@ -1860,12 +1856,8 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
                     *px = make_float4(thr.x * cr, thr.y * cg, thr.z * cb, thr.w); // mk:35-37
                 }
             }
-            if (kNoBar) {
-                item += gridDim.x;
-            } else {
-                __syncthreads(); // L.next[buf] is visible
-                item = uniform(L.next[buf]);
-            }
+            __syncthreads(); // L.next[buf] is visible
+            item = uniform(L.next[buf]);
             iter += 1;
             continue;
         }
@@ -1945,20 +1937,16 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
             L.cnt[(buf * 2 + 0) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(hit_mask));
             L.cnt[(buf * 2 + 1) * kExtendWaves + wave] = static_cast<uint32_t>(__popcll(miss_mask));
         }
-        if (!kNoBar) __syncthreads();
+        __syncthreads();
         WFPT_STAMP(t_synced);
         uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
-        if (kNoBar) { // measurement only (results are wrong): every wave compacts into its own 64 slots, nobody waits for anybody
-            hit_before = miss_before = wave * 64u;
-        } else {
 #pragma unroll
-            for (uint32_t w = 0; w < kExtendWaves; ++w) {
-                const uint32_t hc = uniform(L.cnt[(buf * 2 + 0) * kExtendWaves + w]), mc = uniform(L.cnt[(buf * 2 + 1) * kExtendWaves + w]);
-                hit_before += (w < wave) ? hc : 0u;
-                miss_before += (w < wave) ? mc : 0u;
-                hit_total += hc;
-                miss_total += mc;
-            }
+        for (uint32_t w = 0; w < kExtendWaves; ++w) {
+            const uint32_t hc = uniform(L.cnt[(buf * 2 + 0) * kExtendWaves + w]), mc = uniform(L.cnt[(buf * 2 + 1) * kExtendWaves + w]);
+            hit_before += (w < wave) ? hc : 0u;
+            miss_before += (w < wave) ? mc : 0u;
+            hit_total += hc;
+            miss_total += mc;
         }
         const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
         if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel
@@ -1994,7 +1982,7 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
             acc_cnt[2] += w_visits; acc_cnt[3] += w_leaves; acc_cnt[4] += l_visits;
         }
 #endif
-        item = kNoBar ? item + gridDim.x : uniform(L.next[buf]);
+        item = uniform(L.next[buf]);
         iter += 1;
     }
 #if WFPT_STAMPS
