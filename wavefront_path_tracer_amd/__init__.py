@@ -666,7 +666,9 @@ class PathTracer:
     counter read-backs; `render(spp)` is the same loop resident on the device (no host synchronisation)."""
 
     def __init__(self, scene, rp, max_window_size=0, max_wavefronts=50, miss_floor=128, rng_mode=RNG_DISPATCH,
-                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0, mesh_bins=32, device_bvh=False):
+                 flags=0, tile_rank=0, tile_world=1, device=0, spp=SPP, batch=0, mesh_bins=32, device_bvh=False, bvh=None):
+        """`bvh`: a BVHTree the caller built itself over scene.spheres / scene.triangles AS THEY ARE (the C ABI takes any tree in bvh.rs's
+        layout: siblings at (2k, 2k + 1), at most 63 levels); default: built here like path_tracer.rs:117-118 does."""
         L = lib()
         self.handle = None
         self.scene = scene
@@ -674,7 +676,9 @@ class PathTracer:
         self.render_progress = RenderProgress()
         self.spp = spp
         self.max_wavefronts, self.miss_floor = max_wavefronts, miss_floor
-        if scene.triangles is not None:
+        if bvh is not None:
+            pass
+        elif scene.triangles is not None:
             bvh = BVHTree(len(scene.triangles))
             bvh.build_bvh_tree_triangles(scene.triangles, mesh_bins, device=device if device_bvh else None)
         else:
