@@ -26,4 +26,6 @@ for name, v in zip(("shade (item start -> walk)", "walk", "barrier wait", "compa
 if out[8]:
     print("  wave-level inner visits per wave-item %.1f, leaf rounds %.1f, lanes per inner visit %.1f" % (out[8] / items, out[9] / items, out[10] / max(out[8], 1)))
     print("  walk cycles per wave-level inner visit %.0f" % (out[1] / out[8]))
+if out[11]:
+    print("  of shade: %.0f cycles until the record's slot is known (first_seg table + search of the segment bases), %.0f more until the record has arrived" % (out[11] / items, out[12] / items))
 pt.close()

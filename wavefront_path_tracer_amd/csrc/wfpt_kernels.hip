@@ -1711,9 +1711,14 @@ __device__ __forceinline__ void shade_record(const HitSource &s, float4 ra, floa
 }
 // WAVE_RUN: every lane of the wave shades a hit of the same run of kChunk hits and the same sample (the fused bounce kernel), so the
 // run's segment bounds and the sample's counters are scalars.
+#if WFPT_STAMPS
+#define WFPT_SHADE_STAMPS_PARAM , unsigned long long *shade_stamps = nullptr
+#else
+#define WFPT_SHADE_STAMPS_PARAM
+#endif
 template <bool SCATTER, bool WAVE_RUN = false>
 __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32_t n_hits, wfpt_frame_buffer fb, float &ox, float &oy,
-                                          float &oz, float &dx, float &dy, float &dz, uint32_t &pixel_idx) {
+                                          float &oz, float &dx, float &dy, float &dz, uint32_t &pixel_idx WFPT_SHADE_STAMPS_PARAM) {
     const uint32_t run = WAVE_RUN ? uniform(h / kChunk) : h / kChunk, n_runs = (n_hits + kChunk - 1) / kChunk;
     uint32_t lo = s.in_first_seg[s.co + run];
     uint32_t hi = run + 1 < n_runs ? s.in_first_seg[s.co + run + 1] : (umin(s.ctl->seg_n, s.capacity) + kChunk - 1) / kChunk - 1u;
@@ -1723,7 +1728,13 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
         if (s.in_hit_base[s.co + mid] <= h) lo = mid; else hi = mid - 1u;
     }
     const size_t slot = s.qo + static_cast<size_t>(lo) * kChunk + (h - s.in_hit_base[s.co + lo]);
+#if WFPT_STAMPS
+    if (shade_stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shade_stamps[0] = stamp_now(); } // the record's slot is known
+#endif
     const float4 ra = s.rec_in[2u * slot], rb = s.rec_in[2u * slot + 1u];
+#if WFPT_STAMPS
+    if (shade_stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shade_stamps[1] = stamp_now(); } // the record has arrived
+#endif
     shade_record<SCATTER, WAVE_RUN, WAVE_RUN>(s, ra, rb, __float_as_uint(rb.w), h, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
 }
 
@@ -1823,7 +1834,7 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
     const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6); // (a scalar: what is selected or summed per wave below runs on the scalar unit)
     uint32_t iter = 0;
 #if WFPT_STAMPS
-    unsigned long long acc_cyc[4] = {0, 0, 0, 0};
+    unsigned long long acc_cyc[4] = {0, 0, 0, 0}, acc_search = 0, acc_record = 0; // (the last two: lane 0's view of shade's first two memory levels)
     uint32_t acc_cnt[5] = {0, 0, 0, 0, 0};
 #endif
     while (item < n_items) {
@@ -1892,7 +1903,13 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
             // ---------------- shade (sh:56-156) of hit h of the previous wavefront
             const HitSource src{a.rec_in, a.in_hit_base, a.in_first_seg, a.ctl + smp, image, a.scene.shade_rec, qo, co,
                                 a.capacity, a.rng_mode, a.image_width, a.scene.prim_kind, a.tile};
+#if WFPT_STAMPS
+            unsigned long long sst[2] = {t_item, t_item};
+            shade_hit<TRACE, true>(src, h, n, fb, ox, oy, oz, dx, dy, dz, pixel_idx, sst);
+            if (MODE == kBounceMiddle) { acc_search += sst[0] - t_item; acc_record += sst[1] - sst[0]; }
+#else
             shade_hit<TRACE, true>(src, h, n, fb, ox, oy, oz, dx, dy, dz, pixel_idx);
+#endif
         }
         if (!TRACE) {
             __syncthreads();
@@ -1993,6 +2010,8 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
         atomicAdd(&a.stamps[8], static_cast<unsigned long long>(acc_cnt[2]));
         atomicAdd(&a.stamps[9], static_cast<unsigned long long>(acc_cnt[3]));
         atomicAdd(&a.stamps[10], static_cast<unsigned long long>(acc_cnt[4]));
+        atomicAdd(&a.stamps[11], acc_search);
+        atomicAdd(&a.stamps[12], acc_record);
     }
 #endif
 }
