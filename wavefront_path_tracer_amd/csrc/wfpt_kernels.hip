@@ -669,7 +669,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // The inner-node loop of trace_ray_conservative -- every lane that sits on an inner node (prim_count == 0) visits node pairs until it sits
 // on a leaf or its walk is over (prim_count = kWalkDone) -- written by hand, because what bounds the launch is instruction ISSUE, of both
 // kinds: hipcc's structurizer turns the loop nest (visit | pop with its parent-table walk) into 34-36 scalar mask instructions and
-// 46-47 vector instructions per visit; this loop has 11 scalar and 36 vector ones on the descending path. Same operations on the same
+// 46-47 vector instructions per visit; this loop has 11 scalar and 35 vector ones on the descending path. Same operations on the same
 // values as the C++ statement of the visit (the #else branch below; WFPT_WALK_ASM=0 builds it), in the instruction selection hipcc itself
 // chose for them (v_max3 / v_min / v_min3 / source modifiers), so both give the same bits:
 //   per box: tc = c * b + (-o * b); t_in = max3(tc - h |b|); t_out = min(min(tcx + hx |bx|, tcy + hy |by|), tcz + hz |bz|, nearest)
@@ -743,8 +743,7 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
         // ---- descend (lanes that entered a child)
         "s_and_b64 exec, %[cur], %[mt]\n\t"
         "v_addc_co_u32_e64 %[node], %[mr], 0, %[lf], %[mgo]\n\t" // node = left_first + go_right (the carry out is not used)
-        "v_cndmask_b32_e64 %[t2], 0, 1, %[ml]\n\t"
-        "v_lshl_or_b32 %[trail], %[trail], 1, %[t2]\n\t"
+        "v_addc_co_u32_e64 %[trail], %[mr], %[trail], %[trail], %[ml]\n\t" // trail = trail << 1 | both (trail + trail + carry-in; a trail has at most 31 bits)
         "v_cndmask_b32_e64 %[lf], v35, v43, %[mgo]\n\t"
         "v_cndmask_b32_e64 %[pc], v39, v47, %[mgo]\n\t"
         // ---- pop (lanes that entered neither)
