@@ -794,9 +794,6 @@ __device__ __forceinline__ void descend_asm(uint32_t nodes_lds, uint32_t parent_
 #endif
 }
 
-#ifndef WFPT_WALK_V1
-#define WFPT_WALK_V1 0 // 1: the loop nest of rounds 3-4 (a Traversal object, an `alive` flag): measurement builds only
-#endif
 // Round 5: the walk's state is four vector registers and NO boolean. The scalar unit of a CU serves its four SIMDs with about one
 // instruction per cycle (tools/microbench_valu.hip salu: 0.55 per ns per SIMD), and the loop nest of rounds 3-4 -- an `alive` flag carried
 // through two nested loops and an if / else per visit -- compiled to 36 scalar instructions (exec-mask bookkeeping) per 46 vector
@@ -815,56 +812,6 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
     const float ax = __builtin_fabsf(bx), ay = __builtin_fabsf(by), az = __builtin_fabsf(bz);
     float nearest = 1e30f;
     uint32_t best = 0xffffffffu;
-#if WFPT_WALK_V1
-    Traversal<Trail, ParentT, 0> tr;
-    tr.node = 0; // ex:84: the root's box is never tested
-    tr.left_first = __float_as_uint(nodes_ch[0].w);
-    tr.prim_count = __float_as_uint(nodes_ch[1].w);
-    tr.trail = 0;
-    const bool root_leaf = tr.prim_count != 0u; // the root's own box is never tested (ex:84)
-    uint32_t best_leaf = 0; // the leaf of `best`: left_first | prim_count << 16 (a scene in LDS holds fewer than 2^16 primitives)
-    bool alive = true;
-    uint32_t budget = max_steps; // see trace_ray
-    while (alive) {
-        while (alive && tr.prim_count == 0) {
-            if (WFPT_BUDGET_INNER && budget-- == 0) { alive = false; break; }
-#if WFPT_STAMPS
-            dbg[0] = __builtin_amdgcn_readfirstlane(dbg[0]) + 1u;
-            dbg[2] += 1u;
-#endif
-            const float4 *pair = nodes_ch + 2u * tr.left_first;
-            const float4 lc = pair[0], lh = pair[1], rc = pair[2], rh = pair[3];
-            keep4(lc, lh, rc, rh);
-            const float lcx = fma_(lc.x, bx, nox), lcy = fma_(lc.y, by, noy), lcz = fma_(lc.z, bz, noz);
-            const float l_in = max_(max_(fma_(lh.x, -ax, lcx), fma_(lh.y, -ay, lcy)), fma_(lh.z, -az, lcz));
-            const float l_out = min_(min_(fma_(lh.x, ax, lcx), fma_(lh.y, ay, lcy)), fma_(lh.z, az, lcz));
-            const float rcx = fma_(rc.x, bx, nox), rcy = fma_(rc.y, by, noy), rcz = fma_(rc.z, bz, noz);
-            const float r_in = max_(max_(fma_(rh.x, -ax, rcx), fma_(rh.y, -ay, rcy)), fma_(rh.z, -az, rcz));
-            const float r_out = min_(min_(fma_(rh.x, ax, rcx), fma_(rh.y, ay, rcy)), fma_(rh.z, az, rcz));
-            const bool hit_l = max_(l_in, 0.0f) <= min_(l_out, nearest);
-            const bool hit_r = max_(r_in, 0.0f) <= min_(r_out, nearest);
-            const bool r_nearer = l_in > r_in;
-            const bool go_right = hit_r && (!hit_l || r_nearer); // nearer entry first; ties keep the left child (ex:119)
-            const bool both = hit_l && hit_r;
-            if (!(hit_l || hit_r)) {
-                alive = tr.pop(nodes_ch, pair_parent);
-            } else {
-                tr.node = tr.left_first + (go_right ? 1u : 0u);
-                tr.trail = (tr.trail << 1) | static_cast<Trail>(both ? 1u : 0u);
-                tr.left_first = __float_as_uint(go_right ? rc.w : lc.w);
-                tr.prim_count = __float_as_uint(go_right ? rh.w : lh.w);
-            }
-        }
-        if (alive && budget-- == 0) alive = false;
-        if (alive) { // leaf (ex:86-103); the root's own box is never tested (ex:84)
-#if WFPT_STAMPS
-            dbg[1] = __builtin_amdgcn_readfirstlane(dbg[1]) + 1u;
-#endif
-            visit_leaf<PRIM>(prim_geom, tr.left_first, tr.prim_count, tr.left_first | (tr.prim_count << 16), ox, oy, oz, dx, dy, dz, a, nearest, best, best_leaf);
-            alive = tr.pop(nodes_ch, pair_parent);
-        }
-    }
-#else
     uint32_t node = 0; // ex:84: the root's box is never tested
     uint32_t left_first = __float_as_uint(nodes_ch[0].w), prim_count = __float_as_uint(nodes_ch[1].w);
     Trail trail = 0; // bit i: the far sibling is still pending at the path node i levels above the current one (see Traversal)
@@ -937,7 +884,6 @@ __device__ __forceinline__ bool trace_ray_conservative(const float4 *nodes_ch, c
         }
     }
 #undef WFPT_POP
-#endif
     leaf_box_verdict<PRIM>(prim_geom, best_leaf & 0xffffu, best_leaf >> 16, root_leaf, ox, oy, oz, dx, dy, dz, nearest, best);
     t_out = nearest;
     prim_out = best; // kHandOver: the caller re-traces with the reference's walk
