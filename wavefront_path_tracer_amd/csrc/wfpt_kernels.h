@@ -225,6 +225,10 @@ constexpr int kBounceLast = 2;   // shade (throughput only), miss_kernel    (aft
 #define WFPT_MISS_SEGS 16
 #endif
 constexpr int kMissSegsPerItem = WFPT_MISS_SEGS; // miss work item = this many input segments
+#ifndef WFPT_MISS_EVERY
+#define WFPT_MISS_EVERY 0
+#endif
+constexpr uint32_t kMissEvery = WFPT_MISS_EVERY; // fused bounce launches: every kMissEvery-th ticket is a miss item while both kinds are left; 0 = hit items / miss items + 1, per launch
 
 struct BounceArgs {
     Batch batch;

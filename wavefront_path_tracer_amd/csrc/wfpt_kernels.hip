@@ -24,6 +24,7 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long mask) {
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // a value every lane of the wave holds alike (read through LDS or with a uniform address): as a scalar, so that what is computed
 // from it (offsets, bounds) runs on the scalar unit instead of 64 lanes
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1704,6 +1705,28 @@ __device__ __forceinline__ void shade_hit(const HitSource &s, uint32_t h, uint32
 //      kBounceMiddle: hit items = 512 consecutive hits h of the previous wavefront: shade -> trace; then miss items.
 //      kBounceLast  : after the last extend: shade only multiplies the throughput (sh:84-87); miss items.
 // ================================================================================================
+// Tickets -> work items of a fused bounce launch. Hit items (shade + walk: vector-ALU work) come first in the numbering, miss items (one
+// 16-byte read-modify-write per miss: memory latency, idle ALUs) after them; drawn in that order, every launch ended on a tail of nothing
+// but miss items -- a tenth of its time (round 5: +9 % on the frame). A ticket is therefore mapped so that one miss item follows every
+// `every - 1` hit items, with `every` chosen per launch so that the miss items spread over the whole of it (WFPT_MISS_EVERY fixes it). Both
+// kinds keep their own ascending order (the kernels find an item's sample by walking on from the previous item's).
+struct TicketMap {
+    uint32_t n_hit, every, n_mixed; // (uniform)
+    __device__ __forceinline__ TicketMap(uint32_t n_hit_items, uint32_t n_items, bool mix) : n_hit(n_hit_items) {
+        const uint32_t n_miss = n_items - n_hit_items;
+        every = kMissEvery ? kMissEvery : uniform(umin(umax(n_hit_items / umax(n_miss, 1u), 1u), 62u)) + 1u;
+        n_mixed = mix ? umin(n_miss, n_hit_items / (every - 1u)) : 0u; // miss items placed among the hit items
+    }
+    __device__ __forceinline__ uint32_t item_of(uint32_t t) const {
+        if (t < n_mixed * every) {
+            const uint32_t k = t / every, r = t - k * every;
+            return r == every - 1u ? n_hit + k : k * (every - 1u) + r;
+        }
+        const uint32_t u = t - n_mixed * every, rest_h = n_hit - n_mixed * (every - 1u);
+        return u < rest_h ? n_mixed * (every - 1u) + u : n_hit + n_mixed + (u - rest_h);
+    }
+};
+
 struct BounceLds {
     uint32_t *cnt;     // [2][2][kExtendWaves] per-wave hit / miss counts, double-buffered by iteration parity
     uint32_t *next;    // [2] next work item
@@ -1762,8 +1785,10 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
     uint32_t smp_h = 0, first_h = 0, smp_m = 0, first_m = n_hit_items;
     if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < a.batch.n)
         a.ctl[threadIdx.x].n_in = umin(n_slots, a.capacity); // pt:313-316: counter[2] = rays of the first wavefront (read by scan)
-    uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
+    const TicketMap tickets(n_hit_items, n_items, MODE != kBounceFirst);
+    uint32_t ticket = blockIdx.x;
+    if (ticket >= n_items) return;
+    uint32_t item = tickets.item_of(ticket);
     const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
     if (stage_scene) {
         const float4 *g_staged = EXACT ? g_nodes : a.scene.nodes_ch; // reference boxes, or conservative centre / half-extent boxes
@@ -1782,7 +1807,7 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
     unsigned long long acc_cyc[4] = {0, 0, 0, 0}, acc_search = 0, acc_record = 0; // (the last two: lane 0's view of shade's first two memory levels)
     uint32_t acc_cnt[5] = {0, 0, 0, 0, 0};
 #endif
-    while (item < n_items) {
+    while (ticket < n_items) {
         const uint32_t buf = iter & 1u;
         if (threadIdx.x == 0) L.next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         if (item >= n_hit_items) {
@@ -1813,7 +1838,8 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
                 }
             }
             __syncthreads(); // L.next[buf] is visible
-            item = uniform(L.next[buf]);
+            ticket = uniform(L.next[buf]);
+            item = tickets.item_of(ticket);
             iter += 1;
             continue;
         }
@@ -1858,7 +1884,8 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
         }
         if (!TRACE) {
             __syncthreads();
-            item = uniform(L.next[buf]);
+            ticket = uniform(L.next[buf]);
+            item = tickets.item_of(ticket);
             iter += 1;
             continue;
         }
@@ -1944,7 +1971,8 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
             acc_cnt[2] += w_visits; acc_cnt[3] += w_leaves; acc_cnt[4] += l_visits;
         }
 #endif
-        item = uniform(L.next[buf]);
+        ticket = uniform(L.next[buf]);
+        item = tickets.item_of(ticket);
         iter += 1;
     }
 #if WFPT_STAMPS
@@ -2005,8 +2033,10 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     const uint32_t n_items = MODE == kBounceFirst ? n_hit_items : uniform(plan_m[nb]);
     if (MODE == kBounceFirst && blockIdx.x == 0 && threadIdx.x < nb)
         a.ctl[threadIdx.x].n_in = n_first; // pt:313-316: counter[2] = rays of the first wavefront (read by scan)
-    uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
+    const TicketMap tickets(n_hit_items, n_items, MODE != kBounceFirst);
+    uint32_t ticket = blockIdx.x;
+    if (ticket >= n_items) return;
+    uint32_t item = tickets.item_of(ticket);
     const float4 *g_nodes = reinterpret_cast<const float4 *>(a.scene.nodes);
     if (TRACE) {
         const float4 *g_staged = EXACT ? g_nodes : a.scene.nodes_ch; // reference boxes, or conservative centre / half-extent boxes
@@ -2024,7 +2054,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
     const uint32_t lane = lane_id(), wave = uniform(threadIdx.x >> 6);
     uint32_t idx_h = 0, idx_m = 0; // a workgroup's tickets only grow: the plan is searched on from where the previous item was found
     uint32_t iter = 0;
-    while (item < n_items) {
+    while (ticket < n_items) {
         const uint32_t buf = iter & 1u;
         if (threadIdx.x == 0) s_next[buf] = gridDim.x + atomicAdd(&a.ctl->ticket, 1u);
         if (item >= n_hit_items) {
@@ -2054,7 +2084,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 }
             }
             __syncthreads(); // s_next[buf] is visible
-            item = uniform(s_next[buf]);
+            ticket = uniform(s_next[buf]);
+            item = tickets.item_of(ticket);
             iter += 1;
             continue;
         }
@@ -2129,7 +2160,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         }
         if (!TRACE) {
             __syncthreads();
-            item = uniform(s_next[buf]);
+            ticket = uniform(s_next[buf]);
+            item = tickets.item_of(ticket);
             iter += 1;
             continue;
         }
@@ -2217,7 +2249,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
 #pragma unroll
             for (int j = 0; j < NW; ++j) a.out_cls[(co + seg_out) * NW + j] = total[j];
         }
-        item = uniform(s_next[buf]);
+        ticket = uniform(s_next[buf]);
+        item = tickets.item_of(ticket);
         iter += 1;
     }
 }
