@@ -23,7 +23,7 @@ struct Stamp { unsigned long long cycles, real, r0, r1; };
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2))); // a 128-bit VGPR tuple inline asm can name
 
-enum Kind { FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW,
+enum Kind { VISIT_ASM, VISIT_ASM_PK, FMA, MINMAX, MAX3, CNDMASK, CMP, CMP_CND, RCP, SQRT, ADDU, LSHLADD, FMA_DEP, FMA_SALU, FMA_DSREAD, VISIT_OLD, VISIT_NEW,
             MULF, ADDF, ANDB, LSHL, BFE, CVTUB, ADDC, MOV, MED3, ANDOR, CNDVCC, MINE64, PKFMA, FMAMIX, PERM, MINU, MULLO, MULHI, MAD64, DIVSCALE, DIVFMAS, DIVFIXUP, EXPF, LOGF, READLANE, WRITELANE, LSHLADD64, PKMUL, CVTFU, S_ADD, S_AND64, S_CSEL, S_LOADHIT, RFL_CHAIN, FMA_SALU16, FMA_SALU64, FMA_SAND32, MINMAX_SALU32, VISIT_MIX, N_KINDS };
 
 // one instruction of the class on register x (a, b: loop-invariant VGPRs; m: an SGPR pair holding a lane mask)
@@ -208,6 +208,69 @@ template <int KIND> __global__ __launch_bounds__(256) void kern(Stamp *out, floa
             asm volatile("" ::"v"(n0), "v"(n1), "v"(n2), "v"(n3));
             addr = (addr + 64u * 7u) & 16383u & ~63u;
         }
+        if (KIND == VISIT_ASM || KIND == VISIT_ASM_PK) {
+            // The DESCENDING path of descend_asm (wfpt_kernels.hip), straight-line: node pair from LDS -> two slab tests -> mask logic -> the next
+            // pair's address from the chosen child word. VISIT_ASM: the shipped 18 v_fma_f32 (35 vector + 11 scalar instructions). VISIT_ASM_PK: the
+            // pair stored interleaved (lcx rcx lcy rcy | lcz rcz lhx rhx | lhy rhy lhz rhz | words), 8 v_pk_fma_f32 + 2 v_fma_f32 (27 + 11).
+            unsigned long long m_cur, m_l, m_r, m_go, m_t;
+            float t1, t2;
+            uint32_t lf = addr, trail = 1u, node = 0u, pc = 0u;
+            if (KIND == VISIT_ASM) {
+                asm volatile(
+                    "ds_read_b128 v[32:35], %[lf]\n\tds_read_b128 v[36:39], %[lf] offset:16\n\tds_read_b128 v[40:43], %[lf] offset:32\n\tds_read_b128 v[44:47], %[lf] offset:48\n\t"
+                    "s_mov_b64 %[cur], exec\n\ts_waitcnt lgkmcnt(2)\n\t"
+                    "v_fma_f32 v32, v32, %[bx], %[nox]\n\tv_fma_f32 v33, v33, %[by], %[noy]\n\tv_fma_f32 v34, v34, %[bz], %[noz]\n\t"
+                    "v_fma_f32 %[t1], v36, -|%[bx]|, v32\n\tv_fma_f32 v32, v36, |%[bx]|, v32\n\tv_fma_f32 v36, v37, -|%[by]|, v33\n\t"
+                    "v_fma_f32 v33, v37, |%[by]|, v33\n\tv_fma_f32 v37, v38, -|%[bz]|, v34\n\tv_fma_f32 v34, v38, |%[bz]|, v34\n\t"
+                    "v_max3_f32 %[t1], %[t1], v36, v37\n\tv_min_f32_e32 v32, v32, v33\n\tv_min3_f32 v32, v32, v34, %[nearest]\n\t"
+                    "v_max_f32_e32 v33, 0, %[t1]\n\tv_cmp_le_f32_e64 %[ml], v33, v32\n\ts_waitcnt lgkmcnt(0)\n\t"
+                    "v_fma_f32 v40, v40, %[bx], %[nox]\n\tv_fma_f32 v41, v41, %[by], %[noy]\n\tv_fma_f32 v42, v42, %[bz], %[noz]\n\t"
+                    "v_fma_f32 %[t2], v44, -|%[bx]|, v40\n\tv_fma_f32 v40, v44, |%[bx]|, v40\n\tv_fma_f32 v44, v45, -|%[by]|, v41\n\t"
+                    "v_fma_f32 v41, v45, |%[by]|, v41\n\tv_fma_f32 v45, v46, -|%[bz]|, v42\n\tv_fma_f32 v42, v46, |%[bz]|, v42\n\t"
+                    "v_max3_f32 %[t2], %[t2], v44, v45\n\tv_min_f32_e32 v40, v40, v41\n\tv_min3_f32 v40, v40, v42, %[nearest]\n\t"
+                    "v_max_f32_e32 v41, 0, %[t2]\n\tv_cmp_le_f32_e64 %[mr], v41, v40\n\tv_cmp_gt_f32_e32 vcc, %[t1], %[t2]\n\t"
+                    "s_orn2_b64 %[mt], vcc, %[ml]\n\ts_and_b64 %[mgo], %[mt], %[mr]\n\ts_or_b64 %[mt], %[ml], %[mr]\n\ts_and_b64 %[ml], %[ml], %[mr]\n\t"
+                    "s_and_b64 exec, %[cur], %[mt]\n\t"
+                    "v_addc_co_u32_e64 %[node], %[mr], 0, %[lf], %[mgo]\n\tv_addc_co_u32_e64 %[trail], %[mr], %[trail], %[trail], %[ml]\n\t"
+                    "v_cndmask_b32_e64 %[lf], v35, v43, %[mgo]\n\tv_cndmask_b32_e64 %[pc], v39, v47, %[mgo]\n\t"
+                    "s_andn2_b64 exec, %[cur], %[mt]\n\ts_mov_b64 exec, %[cur]\n\tv_cmp_eq_u32_e32 vcc, 0, %[pc]\n\t"
+                    : [node] "+v"(node), [lf] "+v"(lf), [pc] "+v"(pc), [trail] "+v"(trail), [cur] "=&s"(m_cur), [ml] "=&s"(m_l), [mr] "=&s"(m_r), [mgo] "=&s"(m_go),
+                      [mt] "=&s"(m_t), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                    : [bx] "v"(x[0]), [by] "v"(x[1]), [bz] "v"(x[2]), [nox] "v"(x[3]), [noy] "v"(x[4]), [noz] "v"(x[5]), [nearest] "v"(x[6])
+                    : "vcc", "scc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+            } else {
+                // operand pairs: y[0] = (bx, by), y[1] = (bz, ax), y[2] = (ay, az), y[3] = (nox, noy), y[4] = (noz, -)
+                asm volatile(
+                    "ds_read_b128 v[32:35], %[lf]\n\tds_read_b128 v[36:39], %[lf] offset:16\n\tds_read_b128 v[40:43], %[lf] offset:32\n\tds_read_b128 v[44:47], %[lf] offset:48\n\t"
+                    "s_mov_b64 %[cur], exec\n\ts_waitcnt lgkmcnt(3)\n\t"
+                    "v_pk_fma_f32 v[32:33], v[32:33], %[bxy], %[noxy] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" // tc_x (l, r) = c * bx + nox
+                    "v_pk_fma_f32 v[34:35], v[34:35], %[bxy], %[noxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t" // tc_y
+                    "s_waitcnt lgkmcnt(2)\n\t"
+                    "v_pk_fma_f32 v[36:37], v[36:37], %[bza], %[nozz] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" // tc_z
+                    "v_fma_f32 %[t1], v38, -|%[bx]|, v32\n\tv_fma_f32 %[t2], v39, -|%[bx]|, v33\n\t"     // in_x (l), (r)
+                    "v_pk_fma_f32 v[32:33], v[38:39], %[bza], v[32:33] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" // out_x = h_x * ax + tc_x
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_pk_fma_f32 v[38:39], v[40:41], %[ayz], v[34:35] op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t" // in_y
+                    "v_pk_fma_f32 v[34:35], v[40:41], %[ayz], v[34:35] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"                              // out_y
+                    "v_pk_fma_f32 v[40:41], v[42:43], %[ayz], v[36:37] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t" // in_z
+                    "v_pk_fma_f32 v[36:37], v[42:43], %[ayz], v[36:37] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                              // out_z
+                    "v_max3_f32 %[t1], %[t1], v38, v40\n\tv_max3_f32 %[t2], %[t2], v39, v41\n\t"
+                    "v_min_f32_e32 v32, v32, v34\n\tv_min3_f32 v32, v32, v36, %[nearest]\n\tv_min_f32_e32 v33, v33, v35\n\tv_min3_f32 v33, v33, v37, %[nearest]\n\t"
+                    "v_max_f32_e32 v42, 0, %[t1]\n\tv_cmp_le_f32_e64 %[ml], v42, v32\n\tv_max_f32_e32 v43, 0, %[t2]\n\tv_cmp_le_f32_e64 %[mr], v43, v33\n\t"
+                    "v_cmp_gt_f32_e32 vcc, %[t1], %[t2]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                    "s_orn2_b64 %[mt], vcc, %[ml]\n\ts_and_b64 %[mgo], %[mt], %[mr]\n\ts_or_b64 %[mt], %[ml], %[mr]\n\ts_and_b64 %[ml], %[ml], %[mr]\n\t"
+                    "s_and_b64 exec, %[cur], %[mt]\n\t"
+                    "v_addc_co_u32_e64 %[node], %[mr], 0, %[lf], %[mgo]\n\tv_addc_co_u32_e64 %[trail], %[mr], %[trail], %[trail], %[ml]\n\t"
+                    "v_cndmask_b32_e64 %[lf], v44, v46, %[mgo]\n\tv_cndmask_b32_e64 %[pc], v45, v47, %[mgo]\n\t"
+                    "s_andn2_b64 exec, %[cur], %[mt]\n\ts_mov_b64 exec, %[cur]\n\tv_cmp_eq_u32_e32 vcc, 0, %[pc]\n\t"
+                    : [node] "+v"(node), [lf] "+v"(lf), [pc] "+v"(pc), [trail] "+v"(trail), [cur] "=&s"(m_cur), [ml] "=&s"(m_l), [mr] "=&s"(m_r), [mgo] "=&s"(m_go),
+                      [mt] "=&s"(m_t), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                    : [bxy] "v"(y[0]), [bza] "v"(y[1]), [ayz] "v"(y[2]), [noxy] "v"(y[3]), [nozz] "v"(y[4]), [bx] "v"(x[0]), [nearest] "v"(x[6])
+                    : "vcc", "scc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+            }
+            x[7] += static_cast<float>(node + trail + pc) * 1e-30f; // keeps the results alive
+            addr = ((lf >> 3) * 64u + addr + 64u) & 16383u & ~63u;   // the next pair depends on the chosen child word
+        }
         if (KIND == VISIT_OLD || KIND == VISIT_NEW) {
             // The instruction mix of one inner-node visit of the LDS traversal, as a DEPENDENT computation the way the kernel
             // has it: 4 ds_read_b128 -> wait -> two slab tests -> ordering -> descent (the address of the next trip depends on
@@ -300,15 +363,15 @@ template <int KIND> void run(const char *name, double insts_per_trip, Stamp *d_o
         // chip-wide rate from the launch's wall time (hipEvents), no assumption about placement at all
         const double chip = static_cast<double>(h.size()) * trips * insts_per_trip / (launch_ms * 1e-3);
         printf("%-34s waves/SIMD %d: %7.3f cycles/instr/SIMD  (one wave: %6.2f cycles/instr)  clock %.3f GHz  %6.3f ns/instr/SIMD | %3.0f%% of the waves "
-               "resident together, launch %.2f ms = %.3f T wave-instr/s chip-wide = %.3f per ns per SIMD\n", name,
+               "resident together, launch %.2f ms = %.3f T wave-instr/s chip-wide = %.3f per ns per SIMD (%.2f ns each)\n", name,
                waves_per_simd, per_simd, c / (trips * insts_per_trip), f * 1e-9, per_simd / (f * 1e-9), 100.0 * together / h.size(), launch_ms,
-               chip * 1e-12, chip * 1e-9 / (4.0 * cus));
+               chip * 1e-12, chip * 1e-9 / (4.0 * cus), (4.0 * cus) / (chip * 1e-9));
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
 }
 
 int main(int argc, char **argv) {
-    const bool only_new = argc > 1 && std::string(argv[1]) != "salu"; // "salu": the scalar classes of round 5; any other argument: only the classes added in round 3
+    const bool only_new = argc > 1 && std::string(argv[1]) != "salu" && std::string(argv[1]) != "visit"; // "salu": the scalar classes of round 5; any other argument: only the classes added in round 3
     const bool only_salu = argc > 1 && std::string(argv[1]) == "salu";
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -318,6 +381,14 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_out, sizeof(Stamp) * 4 * cus * 8));
     CK(hipMalloc(&d_sink, 64));
     printf("device: %s, %d CUs; cycles = s_memtime ticks, clock = s_memtime / s_memrealtime x 100 MHz, medians over all waves\n", prop.name, cus);
+    if (argc > 1 && std::string(argv[1]) == "visit") { // round 5: the hand-written inner visit as shipped, and with packed FMAs on an interleaved node pair
+        quick = true;
+        run<FMA>("v_fma_f32", 64, d_out, d_sink, cus);
+        run<PKFMA>("v_pk_fma_f32 (two FMAs per instruction)", 64, d_out, d_sink, cus);
+        run<VISIT_ASM>("descending visit, 18 v_fma (per VISIT)", 1, d_out, d_sink, cus);
+        run<VISIT_ASM_PK>("descending visit, 8 v_pk_fma + 2 v_fma (per VISIT)", 1, d_out, d_sink, cus);
+        return 0;
+    }
     if (only_salu) {
         // Does the scalar unit take issue slots from the vector ALU? Scalar classes alone, then VALU streams with 1/4, 1/2 and 1 scalar
         // instruction per vector instruction (rates are per VALU instruction for the mixed rows, per scalar instruction for the pure ones).
