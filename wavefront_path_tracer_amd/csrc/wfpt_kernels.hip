@@ -225,6 +225,9 @@ __device__ __forceinline__ float hit_bvh_node(float4 bmin, float4 bmax, float ox
 #ifndef WFPT_VISIT4_PARTIAL_SORT
 #define WFPT_VISIT4_PARTIAL_SORT 0 // 1: visit4 brings only the nearest child to the front (measured: profiles/r04_rejected_experiments.txt)
 #endif
+#ifndef WFPT_LEAF_BOX_FUSED
+#define WFPT_LEAF_BOX_FUSED 1 // visit_leaf_in_place gathers the leaf's box in the loop that tests its primitives (one fetch of each)
+#endif
 #ifndef WFPT_LEAF_LANES
 #define WFPT_LEAF_LANES 8 // refill_kernel: lanes that have to wait at a leaf before the wave runs the leaf code
 #endif
@@ -486,14 +489,27 @@ __device__ __forceinline__ void visit_leaf_in_place(const float4 *geom, uint32_t
                                            float dx, float dy, float dz, float ix, float iy, float iz, float a, float &nearest, uint32_t &best) {
     float n2 = nearest;
     uint32_t b2 = best;
+#if WFPT_LEAF_BOX_FUSED
+    // (round 5) the leaf's box is gathered while its primitives are in registers for their tests: with ~9 lanes in a leaf round some lane
+    // accepts a primitive in nearly every round, so the wave ran the second loop -- the primitives fetched again, a dependent round trip --
+    // nearly always anyway
+    float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (uint32_t i = 0; i < count; ++i) {
+        hit_prim<PRIM, true>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
+        grow_prim_box<PRIM>(geom, first + i, lo, hi);
+    }
+#else
     for (uint32_t i = 0; i < count; ++i) hit_prim<PRIM, true>(geom, first + i, ox, oy, oz, dx, dy, dz, a, n2, b2);
+#endif
     // The box's verdict only matters if something changed (a primitive accepted, or a near-tie poisoned the window: n2 = -1):
-    // most leaf visits end here, without the box ever being computed.
+    // most leaf visits end here, without the box ever being tested.
     if (n2 < nearest) {
         bool enter = box_untested || WFPT_EXP_NO_LEAFBOX;
         if (!enter) {
+#if !WFPT_LEAF_BOX_FUSED
             float3_ lo = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
             for (uint32_t i = 0; i < count; ++i) grow_prim_box<PRIM>(geom, first + i, lo, hi);
+#endif
             float tmin, tmax;
             if (LAZY_INV) { ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; } // invDirection (gr:87, sh:153)
             slab_range(make_float4(lo.x, lo.y, lo.z, 0.0f), make_float4(hi.x, hi.y, hi.z, 0.0f), ox, oy, oz, ix, iy, iz, tmin, tmax);
