@@ -9,6 +9,7 @@ for lib in wavefront_path_tracer_amd/libwfpt.so build/libwfpt_*.so; do
   python - "$name" gpurun_out/ab_${tag}_${name}.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[2]))
-print(f"{sys.argv[1]:>14}: {d['value']:9.1f} Mrays/s  {d['ms_per_step']:.4f} ms/step  frac {d['roofline']['frac']:.4f}  {d['stage_ms']}")
+frac = d.get('roofline', {}).get('frac')
+print(f"{sys.argv[1]:>14}: {d['value']:9.1f} Mrays/s  {d['ms_per_step']:.4f} ms/step  frac {frac if frac is None else round(frac, 4)}  {d.get('stage_ms')}")
 PY
 done

@@ -2595,9 +2595,14 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_REFILL_MIN_WAVES) void refill_
         { const unsigned long long vm = __ballot(alive && (cur & kLeafFlag) == 0); if (vm) { st_n[2] += 1; st_n[3] += static_cast<unsigned long long>(__popcll(vm)); } }
 #endif
         if (alive && (cur & kLeafFlag) == 0) {
+#if WFPT_BUDGET_INNER
             if (budget-- == 0) {
                 fin = true;
-            } else {
+            } else
+#endif
+            {
+            // (no step budget on node visits, as in the LDS walk's inner loop: wfpt_create / wfpt_update_scene reject a tree with a cycle
+            // (validate_bvh), the four-wide nodes are collapsed from it, and a walk over a tree visits a node once; leaves keep theirs)
             const Visit4 v = visit4_at(nodes4, s_tile, tile_n, cur, r4, nearest);
             // (the whole wave takes the LDS-only form of the stack operations unless one of its lanes is within three entries of the
             // column's end / holds spilled entries: 0.3 % of the pushes go deeper than kStack4Lds)
