@@ -38,7 +38,8 @@ def body(asm, mangled_part):
 
 KERNELS = {  # mangled fragment: (what it is, scratch bytes allowed)
     "bounce_kernelILi1EjLi0ELb1ELb0E": ("bounce_kernel<middle>, spheres in LDS, default walk", 0),
-    "bounce_kernelILi0EjLi0ELb1ELb0E": ("bounce_kernel<first>", 16),
+    # (the first launch keeps the magic numbers of generate_rays' tile-index division in scratch: loop-invariant, re-loaded once per work item)
+    "bounce_kernelILi0EjLi0ELb1ELb0E": ("bounce_kernel<first>", 24),
     "bounce_binned_kernelILi1EjLi0ELb0ELi4E": ("bounce_binned_kernel<middle>", 0),
     "extend_kernelILb0EjLi0ELb1ELb0E": ("extend_kernel, spheres in LDS, default walk", 0),
     "refill_kernelILi0ELi1ELb1E": ("refill_kernel<first>, triangles, rays from the dense array", 16),

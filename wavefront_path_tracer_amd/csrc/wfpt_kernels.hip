@@ -1101,6 +1101,43 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
     return nearest < 1e30f;
 }
 
+// The eight waves' hit and miss counts of a work item -> this wave's offsets. `cnt` = [16] words in LDS: hits of waves 0-7, misses of waves
+// 0-7 (written by lane 0 of every wave before the item's barrier). One ds_read per lane of the first row, an inclusive scan over the row with
+// four DPP adds, four v_readlane: where the obvious loop over the waves -- (w < wave) ? count : 0 -- compiled to 16 v_readfirstlane and, because
+// hipcc keeps the eight `w < wave` booleans as lane masks in scalar registers it then has to spill, ~32 v_readlane and ~40 scalar instructions.
+#ifndef WFPT_DPP_PREFIX
+#define WFPT_DPP_PREFIX 1
+#endif
+__device__ __forceinline__ void wave_offsets(const uint32_t *cnt, uint32_t wave, uint32_t lane, uint32_t &hit_before, uint32_t &hit_total,
+                                             uint32_t &miss_before, uint32_t &miss_total) {
+#if WFPT_DPP_PREFIX
+    uint32_t v = lane < 16u ? cnt[lane] : 0u;
+    // row_shr:n within the row of 16 lanes, zero shifted in (bound_ctrl): inclusive prefix sums of the row
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, true));
+    hit_total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 7));
+    const uint32_t all = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 15));
+    // (lane wave + 7 holds hits of all waves + misses of waves < wave; lane wave - 1 the hits of waves < wave; wave 0: lane 7 / nothing)
+    const uint32_t m_incl = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(wave + 7u)));
+    const uint32_t h_incl = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>((wave + 15u) & 15u)));
+    hit_before = wave ? h_incl : 0u;
+    miss_before = m_incl - hit_total;
+    miss_total = all - hit_total;
+#else
+    hit_before = miss_before = hit_total = miss_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kExtendWaves; ++w) {
+        const uint32_t hc = uniform(cnt[w]), mc = uniform(cnt[kExtendWaves + w]);
+        hit_before += (w < wave) ? hc : 0u;
+        miss_before += (w < wave) ? mc : 0u;
+        hit_total += hc;
+        miss_total += mc;
+    }
+#endif
+}
+
 // Persistent workgroups of 512 threads (8 waves): stage the scene in LDS once, then trace queue
 // segments of 512 rays handed out by an atomic ticket. A segment's hits / misses are compacted in
 // thread order into the matching segment of the hit / miss queues with wave64 ballots + mbcnt and one
@@ -1229,15 +1266,8 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
             }
         }
         __syncthreads();
-        uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kExtendWaves; ++w) {
-            const uint32_t h = uniform(s_misc[(buf * 2 + 0) * kExtendWaves + w]), m = uniform(s_misc[(buf * 2 + 1) * kExtendWaves + w]);
-            hit_before += (w < wave) ? h : 0u;
-            miss_before += (w < wave) ? m : 0u;
-            hit_total += h;
-            miss_total += m;
-        }
+        uint32_t hit_before, miss_before, hit_total, miss_total;
+        wave_offsets(s_misc + buf * 2u * kExtendWaves, wave, lane, hit_before, hit_total, miss_before, miss_total);
         const size_t seg = qo + static_cast<size_t>(chunk) * kChunk;
         if (hit) { // ex:57-59: payload (t, ray_idx, sphere_idx), slot = rank in thread order
             const size_t slot = seg + hit_before + mbcnt(hit_mask);
@@ -1944,15 +1974,8 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
         }
         __syncthreads();
         WFPT_STAMP(t_synced);
-        uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kExtendWaves; ++w) {
-            const uint32_t hc = uniform(L.cnt[(buf * 2 + 0) * kExtendWaves + w]), mc = uniform(L.cnt[(buf * 2 + 1) * kExtendWaves + w]);
-            hit_before += (w < wave) ? hc : 0u;
-            miss_before += (w < wave) ? mc : 0u;
-            hit_total += hc;
-            miss_total += mc;
-        }
+        uint32_t hit_before, miss_before, hit_total, miss_total;
+        wave_offsets(L.cnt + buf * 2u * kExtendWaves, wave, lane, hit_before, hit_total, miss_before, miss_total);
         const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
         if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel
             const size_t slot = seg + hit_before + mbcnt(hit_mask);
@@ -2223,6 +2246,18 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
         }
         __syncthreads();
         uint32_t before[NW], total[NW];
+#if WFPT_DPP_PREFIX
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { // lane w < 8 holds wave w's packed counts; inclusive scan over the row (see wave_offsets)
+            uint32_t v = lane < kExtendWaves ? s_cnt[(buf * kExtendWaves + lane) * NW + j] : 0u; // fields of at most 512 each: no carries between them
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, true));
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, true));
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, true));
+            total[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 7));
+            const uint32_t incl = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>((wave + 15u) & 15u)));
+            before[j] = wave ? incl : 0u;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < NW; ++j) { before[j] = 0; total[j] = 0; }
 #pragma unroll
@@ -2234,6 +2269,7 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void bounce_
                 total[j] += v;
             }
         }
+#endif
         // where class k starts inside the segment: the totals of the classes before it (packed like the counts)
         uint32_t coff[NW];
 #pragma unroll
@@ -2740,15 +2776,8 @@ __global__ __launch_bounds__(kExtendThreads) void compact_kernel(CompactArgs a) 
         s_cnt[1][wave] = static_cast<uint32_t>(__popcll(miss_mask));
     }
     __syncthreads();
-    uint32_t hit_before = 0, miss_before = 0, hit_total = 0, miss_total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kExtendWaves; ++w) {
-        const uint32_t hc = uniform(s_cnt[0][w]), mc = uniform(s_cnt[1][w]);
-        hit_before += (w < wave) ? hc : 0u;
-        miss_before += (w < wave) ? mc : 0u;
-        hit_total += hc;
-        miss_total += mc;
-    }
+    uint32_t hit_before, miss_before, hit_total, miss_total;
+    wave_offsets(&s_cnt[0][0], wave, lane, hit_before, hit_total, miss_before, miss_total);
     const size_t seg = qo + static_cast<size_t>(chunk) * kChunk;
     if (hit) {
         const size_t slot = seg + hit_before + mbcnt(hit_mask);
