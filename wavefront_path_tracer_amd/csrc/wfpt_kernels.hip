@@ -1977,15 +1977,18 @@ __global__ WFPT_BOUNCE_ATTR void bounce_kernel(BounceArgs a) {
         uint32_t hit_before, miss_before, hit_total, miss_total;
         wave_offsets(L.cnt + buf * 2u * kExtendWaves, wave, lane, hit_before, hit_total, miss_before, miss_total);
         const size_t seg = qo + static_cast<size_t>(seg_out) * kChunk;
+        // (the wave's first slot is a scalar address; a lane adds its 32-bit rank: no 64-bit vector arithmetic per store)
         if (hit) { // the path record shade will read: p = origin + t * direction (sh:91), incoming direction, primitive, pixel
-            const size_t slot = seg + hit_before + mbcnt(hit_mask);
-            a.rec_out[2u * slot] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(pixel_idx));
-            a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
+            float4 *rec = a.rec_out + 2u * (seg + hit_before);
+            const uint32_t rank = mbcnt(hit_mask);
+            rec[2u * rank] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(pixel_idx));
+            rec[2u * rank + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
         }
         if (miss) { // what miss_kernel reads of the ray (mk:29-32)
-            const size_t slot = seg + miss_before + mbcnt(miss_mask);
-            a.mq_out.dy()[slot] = dy;
-            a.mq_out.pixel()[slot] = pixel_idx;
+            const size_t first = seg + miss_before;
+            const uint32_t rank = mbcnt(miss_mask);
+            (a.mq_out.dy() + first)[rank] = dy;
+            (a.mq_out.pixel() + first)[rank] = pixel_idx;
         }
         if (threadIdx.x == 0) {
             a.out_hits[co + seg_out] = hit_total;
