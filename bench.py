@@ -66,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-lds-scene", action="store_true", help="experiment: traverse the scene from HBM / L2 although it fits LDS")
     ap.add_argument("--no-binning", action="store_true",
-                    help="WFPT_FLAG_NO_BINNING (pixel-keyed RNG): the hit queue stays in thread order (a work item = 512 consecutive hits) instead of being binned by cost class")
+                    help="WFPT_FLAG_NO_BINNING: the hit queue stays in thread order (a work item = 512 consecutive hits); the default since round 5, kept for old command lines")
     ap.add_argument("--binning", action="store_true",
                     help="WFPT_FLAG_BINNING (pixel-keyed RNG only): the class-binned loop whatever the size of the slab")
     ap.add_argument("--no-refill", action="store_true", help="mesh scene: fused bounce kernel (lanes keep their ray) instead of dynamic lane refill")

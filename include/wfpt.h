@@ -193,13 +193,14 @@ enum {
                                         more than the test's rounding error) -- same hits, fewer instructions; the library
                                         falls back to the exact test by itself when a camera or an injected ray lies outside
                                         the range that bound covers. Same images bit for bit; for bisecting and proofs. */
-    WFPT_FLAG_NO_BINNING = 1u << 7,  /* WFPT_RNG_PIXEL, scenes in LDS: keep the hit queue in thread order (a work item of the fused
-                                        loop = 512 consecutive hits) instead of storing every segment's hits sorted by cost class
-                                        (the dominant primitive | lambertian | metal | dielectric) and shading / tracing 512 hits of
-                                        ONE class per work item -- the default there for contexts of at least 3/4 Mpixel (+2 %
-                                        measured at 1920x1080; smaller slabs lose to the partly filled work items). Same images bit
-                                        for bit. */
-    WFPT_FLAG_BINNING = 1u << 8      /* WFPT_RNG_PIXEL only: run the class-binned loop whatever the size of the context. With
+    WFPT_FLAG_NO_BINNING = 1u << 7,  /* keep the hit queue in thread order (a work item of the fused loop = 512 consecutive hits). This
+                                        is the default in both RNG modes since the end of round 5 (rounds 4-5 binned contexts of at
+                                        least 3/4 Mpixel in WFPT_RNG_PIXEL by default); the flag is accepted and wins over
+                                        WFPT_FLAG_BINNING. */
+    WFPT_FLAG_BINNING = 1u << 8      /* WFPT_RNG_PIXEL, scenes in LDS: the class-binned loop -- every segment's hits stored sorted by cost
+                                        class (the dominant primitive | lambertian | metal | dielectric), a work item = 512 hits of ONE
+                                        class: 32.8 instead of 29.0 of 64 lanes per vector instruction, and level with the thread-ordered
+                                        loop end to end at 1920x1080 (behind it on smaller slabs), hence opt-in. Same images bit for bit. With
                                         WFPT_RNG_DISPATCH wfpt_create refuses the flag (WFPT_ERR_INVALID_ARGUMENT): shade.wgsl:72 keys
                                         its RNG on the dispatch's thread index, i.e. on the order of the hit queue, which this loop
                                         gives up. (Round 4 carried that order through the binning -- thread indices in the records, a hit

@@ -1,7 +1,7 @@
 """The class-binned fused loop (bounce_binned_kernel): every segment's hits stored sorted by cost class (the
 dominant primitive | lambertian | metal | dielectric), a work item = 512 hits of ONE class. WFPT_RNG_PIXEL only (the order of the queue
-is free there; round 4's dispatch-keyed variant was measured slower and removed in round 5): default for slabs of >= 3/4 Mpixel,
-WFPT_FLAG_BINNING forces it. It must give the oracle's image bit for bit, whatever the sizes, batches, tile shards and scene changes:
+is free there; round 4's dispatch-keyed variant was measured slower and removed in round 5), opt-in: WFPT_FLAG_BINNING asks for it (it was
+the default for slabs of >= 3/4 Mpixel until the thread-ordered loop drew level at the end of round 5). It must give the oracle's image bit for bit, whatever the sizes, batches, tile shards and scene changes:
 the class decides where a record is stored, never what is in it. The general parity tests (tests/test_gpu_parity.py) run the loop too (flags 128 / 256);
 here are the cases that aim at its own machinery."""
 import numpy as np
@@ -73,11 +73,13 @@ def test_binned_loop_on_the_five_sphere_scene_and_a_mesh_in_lds(gpu, orc, rng_mo
 
 
 def test_binned_and_thread_ordered_loops_agree_at_full_size(gpu):
-    """1920x1080, 8 bounces, 3 samples: the binned loop (the default at this size) against the thread-ordered one (which the goldens pin)."""
+    """1920x1080, 8 bounces, 3 samples: the binned loop against the thread-ordered one (the default, which the goldens pin; WFPT_FLAG_NO_BINNING
+    names it and wins over WFPT_FLAG_BINNING)."""
     W = gpu
-    for rng_mode, on, off in ((W.RNG_PIXEL, 0, W.FLAG_NO_BINNING),):
+    for rng_mode, on, off in ((W.RNG_PIXEL, W.FLAG_BINNING, 0), (W.RNG_PIXEL, W.FLAG_BINNING, W.FLAG_BINNING | W.FLAG_NO_BINNING)):
         a = make_tracer(W, "shirley", 1920, 1080, rng_mode=rng_mode, max_wavefronts=8, flags=on, batch=3)
         b = make_tracer(W, "shirley", 1920, 1080, rng_mode=rng_mode, max_wavefronts=8, flags=off, batch=3)
+        assert a.loop_kind == "fused_binned" and b.loop_kind == "fused"
         a.render(3); b.render(3)
         assert_bit_equal(a.accumulated(), b.accumulated(), f"mode {rng_mode}")
         assert np.array_equal(a.wavefront_totals(), b.wavefront_totals())

@@ -102,8 +102,8 @@ CASES = [
 
 @pytest.mark.parametrize("kind,w,h,spp,bounces", CASES)
 @pytest.mark.parametrize("rng_mode", [0, 1])
-# fused bounce launches: hipGraph replay / direct; 4 = WFPT_FLAG_UNFUSED: stage kernels one by one; 128 = WFPT_FLAG_NO_BINNING (the pixel-keyed mode's
-# default is the class-binned loop), 256 = WFPT_FLAG_BINNING (the class-binned loop whatever the size of the slab; pixel-keyed mode only)
+# fused bounce launches: hipGraph replay / direct; 4 = WFPT_FLAG_UNFUSED: stage kernels one by one; 128 = WFPT_FLAG_NO_BINNING (names the default,
+# the thread-ordered queue), 256 = WFPT_FLAG_BINNING (the class-binned loop; pixel-keyed mode only)
 @pytest.mark.parametrize("flags", [0, 2, 4, 6, 128, 256, 258])
 def test_device_resident_loop(gpu, orc, kind, w, h, spp, bounces, rng_mode, flags):
     W = gpu

@@ -20,9 +20,9 @@ line split --split-shade --steps 10 --warmup 2 --cpu-seconds 5 &&
 line unfused --unfused --steps 10 --warmup 2 --cpu-seconds 5 &&
 line exact --exact-traversal --steps 10 --warmup 2 --cpu-seconds 5 &&
 line pixel --rng-mode pixel --steps 10 --warmup 2 --cpu-seconds 5 &&
-line pixel_nobin --rng-mode pixel --no-binning --steps 10 --warmup 2 --no-cpu-baseline &&
+line pixel_binned --rng-mode pixel --binning --steps 10 --warmup 2 --no-cpu-baseline &&
 line mesh --scene mesh --steps 4 --warmup 1 --cpu-seconds 10 &&
-bash tools/profile.sh ${rnd}s && bash tools/profile.sh ${rnd}sp --rng-mode pixel && bash tools/profile_mesh.sh ${rnd}m &&
+bash tools/profile.sh ${rnd}s && bash tools/profile.sh ${rnd}sp --rng-mode pixel --binning && bash tools/profile_mesh.sh ${rnd}m &&
 python tools/scale_probe.py --all-ranks --frames 4 > gpurun_out/${rnd}_scale_probe.txt 2>&1 &&
 python tools/scale_probe.py --all-ranks --frames 3 --spp 256 --batch 128 > gpurun_out/${rnd}_scale_probe_c3.txt 2>&1 &&
 python tools/scale_probe.py --scene mesh --frames 2 > gpurun_out/${rnd}_scale_probe_mesh.txt 2>&1 &&

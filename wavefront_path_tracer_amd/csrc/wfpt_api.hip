@@ -1106,12 +1106,12 @@ static wfpt_ctx *create_impl(const wfpt_params *params, const wfpt_sphere *spher
     // The class-binned loop cuts every class's hits into work items of kChunk, so a wavefront may fill up to kBinClasses - 1 more
     // (partly filled) segments than its rays would: room for them. WFPT_RNG_PIXEL only: the order of the queue is free there
     // (include/wfpt.h, WFPT_FLAG_BINNING).
-    // A small slab gains nothing: every class of every sample ends on a partly filled work item, and the late wavefronts of 1/4 or 1/8
-    // of a 1920x1080 frame are a handful of work items per sample (measured per rank of N = 1 / 2 / 4 / 8, 64 samples in flight:
-    // 18.53 / 9.77 / 5.28 / 3.08 ms binned against 19.08 / 9.85 / 5.14 / 2.90 in thread order), so the default asks for 3/4 Mpixel.
-    const bool auto_on = params->rng_mode == WFPT_RNG_PIXEL && (params->flags & WFPT_FLAG_NO_BINNING) == 0 && c->n_pixels >= (3u << 18);
-    const bool want_binning = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE | WFPT_FLAG_NO_LDS_SCENE)) == 0 &&
-                              params->rng_mode == WFPT_RNG_PIXEL && (auto_on || (params->flags & WFPT_FLAG_BINNING) != 0);
+    // Opt-in (WFPT_FLAG_BINNING) since the end of round 5: rounds 4-5 ran it by default on contexts of >= 3/4 Mpixel, where it was 2-3 % ahead
+    // of the thread-ordered loop; with the miss items handed out among the hit items and the compaction offsets by a DPP scan the two are level
+    // at 1920x1080 (23.02 against 23.04 Grays/s), and small slabs always lost to the partly filled work items at the end of every class
+    // (per rank of N = 4 / 8: 5.28 / 3.08 ms binned against 5.14 / 2.90). WFPT_FLAG_NO_BINNING is accepted and changes nothing.
+    const bool want_binning = (params->flags & (WFPT_FLAG_UNFUSED | WFPT_FLAG_SPLIT_SHADE | WFPT_FLAG_NO_LDS_SCENE | WFPT_FLAG_NO_BINNING)) == 0 &&
+                              params->rng_mode == WFPT_RNG_PIXEL && (params->flags & WFPT_FLAG_BINNING) != 0;
     if (want_binning && cap + kBinClasses * kChunk <= 0xffffffffull) {
         cap += kBinClasses * kChunk;
         c->bin_capable = true;
