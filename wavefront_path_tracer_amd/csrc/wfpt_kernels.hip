@@ -1111,6 +1111,7 @@ __device__ __forceinline__ bool trace_ray4(const float4 *nodes4, const float4 *p
 __device__ __forceinline__ void wave_offsets(const uint32_t *cnt, uint32_t wave, uint32_t lane, uint32_t &hit_before, uint32_t &hit_total,
                                              uint32_t &miss_before, uint32_t &miss_total) {
 #if WFPT_DPP_PREFIX
+    static_assert(kExtendWaves == 8, "the sixteen counts are one DPP row");
     uint32_t v = lane < 16u ? cnt[lane] : 0u;
     // row_shr:n within the row of 16 lanes, zero shifted in (bound_ctrl): inclusive prefix sums of the row
     v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, true));
