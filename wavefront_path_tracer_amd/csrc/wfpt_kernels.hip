@@ -1270,21 +1270,25 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         uint32_t hit_before, miss_before, hit_total, miss_total;
         wave_offsets(s_misc + buf * 2u * kExtendWaves, wave, lane, hit_before, hit_total, miss_before, miss_total);
         const size_t seg = qo + static_cast<size_t>(chunk) * kChunk;
+        // (the wave's first slot is a scalar address; a lane adds its 32-bit rank: no 64-bit vector arithmetic per store)
         if (hit) { // ex:57-59: payload (t, ray_idx, sphere_idx), slot = rank in thread order
-            const size_t slot = seg + hit_before + mbcnt(hit_mask);
-            a.hq.t()[slot] = t;
-            a.hq.prim()[slot] = prim;
-            a.hq.ridx()[slot] = idx;
+            const size_t first = seg + hit_before;
+            const uint32_t rank = mbcnt(hit_mask);
+            (a.hq.t() + first)[rank] = t;
+            (a.hq.prim() + first)[rank] = prim;
+            (a.hq.ridx() + first)[rank] = idx;
             if (a.rec_out) { // what shade will need of this hit, in one place: p = origin + t * direction (sh:91), the direction, pixel, primitive
-                a.rec_out[2u * slot] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(q.pixel()[idx]));
-                a.rec_out[2u * slot + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
+                float4 *rec = a.rec_out + 2u * first;
+                rec[2u * rank] = make_float4(ox + t * dx, oy + t * dy, oz + t * dz, __uint_as_float(q.pixel()[idx]));
+                rec[2u * rank + 1u] = make_float4(dx, dy, dz, __uint_as_float(prim));
             }
         }
         if (miss) { // ex:61, plus what miss_kernel reads of the ray (mk:29-32)
-            const size_t slot = seg + miss_before + mbcnt(miss_mask);
-            a.mq.ridx()[slot] = idx;
-            a.mq.dy()[slot] = dy;
-            a.mq.pixel()[slot] = q.pixel()[idx];
+            const size_t first = seg + miss_before;
+            const uint32_t rank = mbcnt(miss_mask);
+            (a.mq.ridx() + first)[rank] = idx;
+            (a.mq.dy() + first)[rank] = dy;
+            (a.mq.pixel() + first)[rank] = q.pixel()[idx];
         }
         if (threadIdx.x == 0) {
             a.chunk_hits[co + chunk] = hit_total;
@@ -1293,12 +1297,15 @@ __global__ __launch_bounds__(kExtendThreads, WFPT_EXTEND_MIN_WAVES) void extend_
         if (a.partition) {
 #pragma unroll
             for (uint32_t m = 0; m < 3; ++m) {
-                uint32_t before = 0, total = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < kExtendWaves; ++w) {
-                    const uint32_t cnt = uniform(s_mat[(buf * 3 + m) * kExtendWaves + w]);
-                    before += (w < wave) ? cnt : 0u;
-                    total += cnt;
+                uint32_t before, total;
+                {
+                    uint32_t v = lane < kExtendWaves ? s_mat[(buf * 3 + m) * kExtendWaves + lane] : 0u; // inclusive scan over the row (see wave_offsets)
+                    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, true));
+                    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, true));
+                    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, true));
+                    total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 7));
+                    const uint32_t incl = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>((wave + 15u) & 15u)));
+                    before = wave ? incl : 0u;
                 }
                 if (mclass == m) // entry = the hit's rank within the segment's hit queue; lists stay ascending
                     a.mat_list[m * a.mat_list_mstride + seg + before + mbcnt(mat_mask[m])] =
